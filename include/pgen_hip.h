@@ -1,0 +1,143 @@
+/*
+ * pgen_hip.h — C ABI of libpgen_hip.so, the MI355X (gfx950) engine for the
+ * one hot path of teoremma/pgen-rs: fixed-width .pgen (storage mode 0x02)
+ * variant records -> 2-bit hard-call unpack -> kept-sample select -> VCF GT
+ * text.  This is the drop-in boundary: plain pointers and sizes, no C++ or
+ * torch types.  The reference has no FFI of its own (it is one private Rust
+ * function), so each entry point cites the reference lines it replaces;
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * Reference seam: /root/reference/src/pfile.rs:156-192 (Pfile::output_vcf hot
+ * loop), :196-200 (variant_record_size), :38-76 (header), :165 (record offset).
+ *
+ * Error convention: every call returns int, 0 = PGENHIP_OK, negative =
+ * pgenhip_status.  Nothing throws or aborts across the boundary (the
+ * reference panics at src/pfile.rs:47,53,69,169,170,173; a host maps a
+ * negative status to a non-zero exit + stderr).  There is NO CPU fallback:
+ * without a usable HIP device pgenhip_create fails with
+ * PGENHIP_ERR_NO_DEVICE / PGENHIP_ERR_HIP.
+ *
+ * Threading: a ctx is bound to one device and is not thread-safe; use one
+ * ctx per device per host thread.  Distinct ctxs are independent.
+ */
+#ifndef PGEN_HIP_H
+#define PGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGENHIP_ABI_VERSION 1u
+
+typedef enum pgenhip_status {
+    PGENHIP_OK = 0,
+    PGENHIP_ERR_BAD_ARG = -1,     /* NULL/zero/misordered argument */
+    PGENHIP_ERR_HIP = -2,         /* a HIP runtime call failed; see pgenhip_last_error_detail */
+    PGENHIP_ERR_OOM = -3,         /* host or device allocation failed */
+    PGENHIP_ERR_INDEX_RANGE = -4, /* kept sample index >= sample_count (ref: slice panic, src/pfile.rs:173) */
+    PGENHIP_ERR_BAD_MAGIC = -5,   /* src/pfile.rs:47 */
+    PGENHIP_ERR_BAD_MODE = -6,    /* src/pfile.rs:53 (only storage mode 0x02) */
+    PGENHIP_ERR_BAD_FLAGS = -7,   /* src/pfile.rs:69 (byte 11 must be 0x40) */
+    PGENHIP_ERR_NO_DEVICE = -8,   /* no HIP device / ordinal out of range */
+    PGENHIP_ERR_TOO_LARGE = -9,   /* a size does not fit the kernel's index types */
+    PGENHIP_ERR_IO = -10          /* file read/write failed (ref: unwrap at src/pfile.rs:169-170) */
+} pgenhip_status;
+
+typedef struct pgenhip_ctx pgenhip_ctx;
+
+/* ---- library-level ---------------------------------------------------- */
+uint32_t pgenhip_abi_version(void);
+const char *pgenhip_strerror(int status);
+/* thread-local detail string of the last failing call (HIP error text etc.) */
+const char *pgenhip_last_error_detail(void);
+int pgenhip_device_count(int *count);
+
+/* ---- format geometry (host-side, pure) -------------------------------- */
+/* src/pfile.rs:196-200  Pfile::variant_record_size: ceil(2*N/8), u32 like the reference */
+uint32_t pgenhip_variant_record_size(uint32_t sample_count);
+/* src/pfile.rs:44-69  the 12-byte header: magic 6C 1B, mode 02, u32 LE variants, u32 LE samples, 0x40 */
+int pgenhip_parse_header(const uint8_t header[12], uint32_t *variant_count, uint32_t *sample_count);
+/* src/pfile.rs:165  byte offset of record var_idx in the file; computed in u64
+ * (the reference multiplies in u32 and wraps at var_idx*R >= 2^32 — SURVEY.md F5). */
+uint64_t pgenhip_record_offset(uint64_t var_idx, uint32_t record_size);
+
+/* ---- context ---------------------------------------------------------- */
+/* Binds a device and the kept-sample list (src/pfile.rs:128 sam_idx_rcs; the
+ * list filter_metadata :319-333 builds is strictly ascending, and that is
+ * required here).  kept_idx == NULL means "all samples" (K = N fast path);
+ * otherwise kept_idx is a HOST array of kept_count indices, copied.
+ * kept_count may be 0 (every row is then just "\n"). */
+int pgenhip_create(pgenhip_ctx **ctx, int device_ordinal, uint32_t sample_count,
+                   const uint32_t *kept_idx, uint32_t kept_count, uint32_t flags);
+int pgenhip_destroy(pgenhip_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the ctx's own. NULL restores the own stream. */
+int pgenhip_set_stream(pgenhip_ctx *ctx, void *hip_stream);
+uint32_t pgenhip_sample_count(const pgenhip_ctx *ctx);
+uint32_t pgenhip_kept_count(const pgenhip_ctx *ctx);
+/* 4*K + 1: bytes one variant's GT segment occupies (src/pfile.rs:186-190) */
+uint64_t pgenhip_gt_row_bytes(const pgenhip_ctx *ctx);
+
+/* ---- the hot path (device-resident, asynchronous on the ctx stream) ---- */
+/* kernel selection for pgenhip_decode_emit flags (0 = automatic) */
+#define PGENHIP_KERNEL_AUTO 0u
+#define PGENHIP_KERNEL_ROWS 1u   /* general row-tiled kernel (any stride/alignment, list gather) */
+#define PGENHIP_KERNEL_FLAT 2u   /* dense all-samples stream kernel (out_stride == 4N+1) */
+#define PGENHIP_KERNEL_SCAN 3u   /* kept-subset scan + wave ballot/popcount compaction */
+#define PGENHIP_KERNEL_MASK 0xFu
+
+/* src/pfile.rs:165-190 for a block of n_variants kept variants.
+ *   row j reads the record at d_records + r*record_stride, r = d_variant_idx ? d_variant_idx[j] : j
+ *   (record layout: sample s in byte s/4, bits 2*(s%4), LSB first — :172-175)
+ *   and writes K x {'\t',a,'/',b} + '\n' = 4K+1 bytes at d_out + j*out_stride (:177-190).
+ * All pointers are DEVICE pointers; any alignment and any strides with
+ * record_stride >= R, out_stride >= 4K+1 (or n_variants <= 1).  Bytes of d_out
+ * outside the n_variants segments are not touched.  No allocation, no
+ * synchronisation: the launch is queued on the ctx stream (graph-capturable). */
+int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
+                        const uint32_t *d_variant_idx, uint32_t n_variants,
+                        void *d_out, uint64_t out_stride, uint32_t flags);
+
+/* Full VCF body lines (src/pfile.rs:156-192): line j = prefix bytes
+ * d_prefix_blob[d_prefix_off[j] .. d_prefix_off[j+1]) (pvar columns + '\t' each,
+ * then "GT", :157-161) + GT segment + '\n', written at d_out + d_line_off[j].
+ * d_prefix_off/d_line_off are device arrays of n_variants+1 u64 with
+ * d_line_off[j+1]-d_line_off[j] == prefix_len(j) + 4K + 1 (lines packed back to back);
+ * max_prefix_bytes is a host-known upper bound of any prefix length (sizes the grid). */
+int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
+                       const uint32_t *d_variant_idx, uint32_t n_variants,
+                       const void *d_prefix_blob, const uint64_t *d_prefix_off,
+                       const uint64_t *d_line_off, uint64_t max_prefix_bytes,
+                       void *d_out, uint32_t flags);
+
+/* Block until everything queued on the ctx stream has finished. */
+int pgenhip_wait(pgenhip_ctx *ctx);
+
+/* hipEvent pair on the ctx stream: start ... launches ... stop -> elapsed ms (stop synchronises). */
+int pgenhip_timer_start(pgenhip_ctx *ctx);
+int pgenhip_timer_stop(pgenhip_ctx *ctx, float *elapsed_ms);
+
+/* ---- device / pinned memory for hosts that do not link HIP themselves --- */
+int pgenhip_device_malloc(pgenhip_ctx *ctx, void **d_ptr, size_t bytes);
+int pgenhip_device_free(pgenhip_ctx *ctx, void *d_ptr);
+int pgenhip_host_malloc_pinned(pgenhip_ctx *ctx, void **h_ptr, size_t bytes);
+int pgenhip_host_free_pinned(pgenhip_ctx *ctx, void *h_ptr);
+/* asynchronous on the ctx stream (truly async only from/to pinned host memory) */
+int pgenhip_memcpy_h2d(pgenhip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int pgenhip_memcpy_d2h(pgenhip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* ---- synthetic records generated on the device --------- */
+#define PGENHIP_SYNTH_DIRTY_PAD 1u
+/* record bytes of variant v = LE words splitmix64(seed + (v << 20) + word_idx), truncated to R;
+ * pad bits of the last byte zeroed unless PGENHIP_SYNTH_DIRTY_PAD.  Bit-exact twin of the
+ * oracle's pgo_synth_records. */
+int pgenhip_synth_records(pgenhip_ctx *ctx, void *d_dst, uint64_t record_stride,
+                          uint64_t first_variant, uint32_t n_variants,
+                          uint64_t seed, uint32_t flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

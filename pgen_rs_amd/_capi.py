@@ -1,0 +1,101 @@
+"""ctypes binding of ``libpgen_hip.so`` (the C ABI in ``include/pgen_hip.h``).
+
+There is no fallback: if the shared library is missing this module raises at import, and if
+no HIP device is usable ``pgenhip_create`` returns ``PGENHIP_ERR_NO_DEVICE``.
+
+torch is imported first on purpose: the PyTorch-ROCm wheel bundles its own
+``libamdhip64.so.7``; loading it before our library makes the dynamic linker bind our
+``DT_NEEDED libamdhip64.so.7`` to that same runtime, so device pointers from torch tensors and
+our kernel launches live in one HIP runtime instance.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import torch  # noqa: F401  (must precede CDLL — see module docstring)
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libpgen_hip.so"
+
+OK = 0
+ERR_BAD_ARG = -1
+ERR_HIP = -2
+ERR_OOM = -3
+ERR_INDEX_RANGE = -4
+ERR_BAD_MAGIC = -5
+ERR_BAD_MODE = -6
+ERR_BAD_FLAGS = -7
+ERR_NO_DEVICE = -8
+ERR_TOO_LARGE = -9
+ERR_IO = -10
+
+KERNEL_AUTO = 0
+KERNEL_ROWS = 1
+KERNEL_FLAT = 2
+KERNEL_SCAN = 3
+SYNTH_DIRTY_PAD = 1
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+ctx_p = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/pgen_hip.h declares
+PROTOTYPES = {
+    "pgenhip_abi_version": (C.c_uint32, []),
+    "pgenhip_strerror": (C.c_char_p, [C.c_int]),
+    "pgenhip_last_error_detail": (C.c_char_p, []),
+    "pgenhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pgenhip_variant_record_size": (C.c_uint32, [C.c_uint32]),
+    "pgenhip_parse_header": (C.c_int, [C.c_char_p, u32p, u32p]),
+    "pgenhip_record_offset": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+    "pgenhip_create": (C.c_int, [C.POINTER(ctx_p), C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "pgenhip_destroy": (C.c_int, [ctx_p]),
+    "pgenhip_set_stream": (C.c_int, [ctx_p, C.c_void_p]),
+    "pgenhip_sample_count": (C.c_uint32, [ctx_p]),
+    "pgenhip_kept_count": (C.c_uint32, [ctx_p]),
+    "pgenhip_gt_row_bytes": (C.c_uint64, [ctx_p]),
+    "pgenhip_decode_emit": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]),
+    "pgenhip_emit_lines": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
+    "pgenhip_wait": (C.c_int, [ctx_p]),
+    "pgenhip_timer_start": (C.c_int, [ctx_p]),
+    "pgenhip_timer_stop": (C.c_int, [ctx_p, C.POINTER(C.c_float)]),
+    "pgenhip_device_malloc": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "pgenhip_device_free": (C.c_int, [ctx_p, C.c_void_p]),
+    "pgenhip_host_malloc_pinned": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "pgenhip_host_free_pinned": (C.c_int, [ctx_p, C.c_void_p]),
+    "pgenhip_memcpy_h2d": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pgenhip_memcpy_d2h": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pgenhip_synth_records": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]),
+}
+
+
+class PgenHipError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        detail = lib.pgenhip_last_error_detail().decode(errors="replace")
+        msg = lib.pgenhip_strerror(status).decode()
+        super().__init__(f"{where}: {msg} (status {status}){': ' + detail if detail else ''}")
+
+
+def _load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing — the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback."
+        )
+    handle = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return handle
+
+
+lib = _load()
+
+
+def check(status: int, where: str) -> None:
+    if status != OK:
+        raise PgenHipError(status, where)

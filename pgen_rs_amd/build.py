@@ -1,0 +1,87 @@
+"""Builds the native pieces in-tree (so they travel to the GPU box with the snapshot).
+
+* ``pgen_rs_amd/libpgen_hip.so`` — HIP kernels + C ABI, ``hipcc --offload-arch=gfx950``.
+* ``oracle/libpgen_oracle.so``   — the CPU oracle (test infrastructure), ``gcc``.
+
+hipcc cross-compiles for gfx950 without a GPU present.  Re-builds only when a source is newer
+than its target.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_ROOT = PKG_DIR.parent
+CSRC = PKG_DIR / "csrc"
+HIP_LIB = PKG_DIR / "libpgen_hip.so"
+ORACLE_DIR = REPO_ROOT / "oracle"
+ORACLE_LIB = ORACLE_DIR / "libpgen_oracle.so"
+
+HIP_SOURCES = ["capi.hip", "gt_rows.hip"]
+HIPCC_FLAGS = [
+    "-O3",
+    "-std=c++17",
+    "--offload-arch=gfx950",
+    "-fPIC",
+    "-shared",
+    "-Wall",
+    "-Wextra",
+    "-Wno-unused-parameter",
+    "-fno-gpu-rdc",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libpgen_hip.so)")
+
+
+def _stale(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def _run(cmd: list[str], cwd: Path) -> None:
+    proc = subprocess.run(cmd, cwd=str(cwd), capture_output=True, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout)
+        sys.stderr.write(proc.stderr)
+        raise RuntimeError(f"build command failed ({proc.returncode}): {' '.join(cmd)}")
+    if proc.stderr.strip():
+        sys.stderr.write(proc.stderr)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> Path:
+    srcs = [CSRC / s for s in HIP_SOURCES]
+    deps = srcs + sorted(CSRC.glob("*.h")) + [REPO_ROOT / "include" / "pgen_hip.h", Path(__file__)]
+    if force or _stale(HIP_LIB, deps):
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-I", str(REPO_ROOT / "include"), "-o", str(HIP_LIB), *map(str, srcs)]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd, CSRC)
+    return HIP_LIB
+
+
+def build_oracle(force: bool = False) -> Path:
+    deps = [ORACLE_DIR / "pgen_oracle.c", ORACLE_DIR / "pgen_oracle.h"]
+    if force or _stale(ORACLE_LIB, deps):
+        _run(["make", "-C", str(ORACLE_DIR), "libpgen_oracle.so"], REPO_ROOT)
+    return ORACLE_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_hip(force=force, verbose=verbose)
+    build_oracle(force=force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built", HIP_LIB, "and", ORACLE_LIB)

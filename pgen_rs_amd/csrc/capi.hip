@@ -1,0 +1,368 @@
+// capi.hip — the extern "C" boundary of libpgen_hip.so (declared in include/pgen_hip.h).
+// Host-side argument checking, context/stream ownership and kernel selection; no CPU compute
+// path exists here: every decode goes through a gfx950 kernel or fails with a status code.
+#include "../../include/pgen_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <string>
+
+#include "kernels.h"
+
+using namespace pgenhip;
+
+struct pgenhip_ctx {
+    int device = 0;
+    int num_cus = 256;
+    uint32_t sample_count = 0;
+    uint32_t record_size = 0;
+    uint32_t kept_count = 0;
+    bool subset = false;
+    uint32_t *d_kept = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr;
+    hipEvent_t ev_stop = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_detail;
+
+int fail(int status, const char *what)
+{
+    g_detail = what ? what : "";
+    return status;
+}
+
+int fail_hip(hipError_t e, const char *where)
+{
+    g_detail = std::string(where) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();  // clear the sticky error
+    return (e == hipErrorOutOfMemory) ? PGENHIP_ERR_OOM : PGENHIP_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t e__ = (expr);                           \
+        if (e__ != hipSuccess) return fail_hip(e__, #expr); \
+    } while (0)
+
+int bind(const pgenhip_ctx *ctx)
+{
+    if (!ctx) return fail(PGENHIP_ERR_BAD_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return PGENHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t pgenhip_abi_version(void) { return PGENHIP_ABI_VERSION; }
+
+const char *pgenhip_strerror(int status)
+{
+    switch (status) {
+        case PGENHIP_OK: return "ok";
+        case PGENHIP_ERR_BAD_ARG: return "bad argument";
+        case PGENHIP_ERR_HIP: return "HIP runtime error";
+        case PGENHIP_ERR_OOM: return "out of memory";
+        case PGENHIP_ERR_INDEX_RANGE: return "kept sample index out of range";
+        case PGENHIP_ERR_BAD_MAGIC: return "not a .pgen file (magic bytes != 6C 1B)";
+        case PGENHIP_ERR_BAD_MODE: return "unsupported .pgen storage mode (only 0x02 fixed-width)";
+        case PGENHIP_ERR_BAD_FLAGS: return "unexpected .pgen header flag byte (expected 0x40)";
+        case PGENHIP_ERR_NO_DEVICE: return "no usable HIP device";
+        case PGENHIP_ERR_TOO_LARGE: return "size exceeds kernel index range";
+        case PGENHIP_ERR_IO: return "I/O error";
+        default: return "unknown status";
+    }
+}
+
+const char *pgenhip_last_error_detail(void) { return g_detail.c_str(); }
+
+int pgenhip_device_count(int *count)
+{
+    if (!count) return fail(PGENHIP_ERR_BAD_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail_hip(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return PGENHIP_OK;
+}
+
+// src/pfile.rs:196-200
+uint32_t pgenhip_variant_record_size(uint32_t sample_count)
+{
+    uint32_t bit_size = sample_count * 2u;
+    return bit_size / 8u + ((bit_size % 8u) ? 1u : 0u);
+}
+
+// src/pfile.rs:44-69
+int pgenhip_parse_header(const uint8_t header[12], uint32_t *variant_count, uint32_t *sample_count)
+{
+    if (!header || !variant_count || !sample_count) return fail(PGENHIP_ERR_BAD_ARG, "NULL argument");
+    if (header[0] != 0x6C || header[1] != 0x1B) return fail(PGENHIP_ERR_BAD_MAGIC, "magic");
+    if (header[2] != 0x02) return fail(PGENHIP_ERR_BAD_MODE, "storage mode");
+    *variant_count = (uint32_t)header[3] | (uint32_t)header[4] << 8 | (uint32_t)header[5] << 16 | (uint32_t)header[6] << 24;
+    *sample_count = (uint32_t)header[7] | (uint32_t)header[8] << 8 | (uint32_t)header[9] << 16 | (uint32_t)header[10] << 24;
+    if (header[11] != 0x40) return fail(PGENHIP_ERR_BAD_FLAGS, "flag byte");
+    return PGENHIP_OK;
+}
+
+// src/pfile.rs:165, widened before the multiply
+uint64_t pgenhip_record_offset(uint64_t var_idx, uint32_t record_size)
+{
+    return 12ull + var_idx * (uint64_t)record_size;
+}
+
+int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
+                   const uint32_t *kept_idx, uint32_t kept_count, uint32_t flags)
+{
+    (void)flags;
+    if (!out) return fail(PGENHIP_ERR_BAD_ARG, "ctx out-pointer is NULL");
+    *out = nullptr;
+    if (sample_count > 0x7FFFFFFFu) return fail(PGENHIP_ERR_TOO_LARGE, "sample_count > 2^31-1");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(PGENHIP_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(PGENHIP_ERR_NO_DEVICE, "device ordinal out of range");
+    if (kept_idx) {
+        for (uint32_t k = 0; k < kept_count; k++) {
+            if (kept_idx[k] >= sample_count) return fail(PGENHIP_ERR_INDEX_RANGE, "kept_idx entry >= sample_count");
+            if (k && kept_idx[k] <= kept_idx[k - 1]) return fail(PGENHIP_ERR_BAD_ARG, "kept_idx not strictly ascending");
+        }
+    }
+    pgenhip_ctx *ctx = new (std::nothrow) pgenhip_ctx();
+    if (!ctx) return fail(PGENHIP_ERR_OOM, "ctx");
+    ctx->device = device_ordinal;
+    ctx->sample_count = sample_count;
+    ctx->record_size = pgenhip_variant_record_size(sample_count);
+    ctx->subset = kept_idx != nullptr;
+    ctx->kept_count = kept_idx ? kept_count : sample_count;
+
+    int rc = PGENHIP_OK;
+    do {
+        if ((e = hipSetDevice(device_ordinal)) != hipSuccess) { rc = fail_hip(e, "hipSetDevice"); break; }
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) { rc = fail_hip(e, "hipGetDeviceProperties"); break; }
+        ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail_hip(e, "hipStreamCreate"); break; }
+        ctx->stream = ctx->own_stream;
+        if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) { rc = fail_hip(e, "hipEventCreate"); break; }
+        if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) { rc = fail_hip(e, "hipEventCreate"); break; }
+        if (ctx->subset) {
+            size_t bytes = (size_t)(kept_count ? kept_count : 1u) * sizeof(uint32_t);
+            if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_kept), bytes)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(kept_idx)"); break; }
+            if (kept_count) {
+                if ((e = hipMemcpy(ctx->d_kept, kept_idx, (size_t)kept_count * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(kept_idx)"); break; }
+            }
+        }
+    } while (0);
+    if (rc != PGENHIP_OK) {
+        std::string keep = g_detail;
+        pgenhip_destroy(ctx);
+        g_detail = keep;
+        return rc;
+    }
+    *out = ctx;
+    return PGENHIP_OK;
+}
+
+int pgenhip_destroy(pgenhip_ctx *ctx)
+{
+    if (!ctx) return PGENHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->d_kept) (void)hipFree(ctx->d_kept);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return PGENHIP_OK;
+}
+
+int pgenhip_set_stream(pgenhip_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return fail(PGENHIP_ERR_BAD_ARG, "ctx is NULL");
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return PGENHIP_OK;
+}
+
+uint32_t pgenhip_sample_count(const pgenhip_ctx *ctx) { return ctx ? ctx->sample_count : 0u; }
+uint32_t pgenhip_kept_count(const pgenhip_ctx *ctx) { return ctx ? ctx->kept_count : 0u; }
+uint64_t pgenhip_gt_row_bytes(const pgenhip_ctx *ctx) { return ctx ? 4ull * ctx->kept_count + 1ull : 0ull; }
+
+static int fill_args(pgenhip_ctx *ctx, EmitArgs &a, const void *d_records, uint64_t record_stride,
+                     const uint32_t *d_variant_idx, uint32_t n_variants, void *d_out)
+{
+    if (n_variants && (!d_out)) return fail(PGENHIP_ERR_BAD_ARG, "d_out is NULL");
+    if (n_variants && ctx->record_size && !d_records) return fail(PGENHIP_ERR_BAD_ARG, "d_records is NULL");
+    if (n_variants > 1 && !d_variant_idx && record_stride < ctx->record_size)
+        return fail(PGENHIP_ERR_BAD_ARG, "record_stride < record size");
+    a.records = static_cast<const uint8_t *>(d_records);
+    a.record_stride = record_stride;
+    a.variant_idx = d_variant_idx;
+    a.n_variants = n_variants;
+    a.sample_count = ctx->sample_count;
+    a.record_size = ctx->record_size;
+    a.kept_idx = ctx->subset ? ctx->d_kept : nullptr;
+    a.kept_count = ctx->kept_count;
+    a.out = static_cast<uint8_t *>(d_out);
+    a.out_stride = 0;
+    a.prefix_blob = nullptr;
+    a.prefix_off = nullptr;
+    a.line_off = nullptr;
+    a.max_line_bytes = 0;
+    return PGENHIP_OK;
+}
+
+int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
+                        const uint32_t *d_variant_idx, uint32_t n_variants,
+                        void *d_out, uint64_t out_stride, uint32_t flags)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    EmitArgs a;
+    rc = fill_args(ctx, a, d_records, record_stride, d_variant_idx, n_variants, d_out);
+    if (rc) return rc;
+    if (n_variants > 1 && out_stride < 4ull * ctx->kept_count + 1ull)
+        return fail(PGENHIP_ERR_BAD_ARG, "out_stride < 4K+1");
+    a.out_stride = out_stride;
+    if (n_variants == 0) return PGENHIP_OK;
+
+    const uint32_t which = flags & PGENHIP_KERNEL_MASK;
+    switch (which) {
+        case PGENHIP_KERNEL_AUTO:
+        case PGENHIP_KERNEL_ROWS:
+            HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        default:
+            return fail(PGENHIP_ERR_BAD_ARG, "requested kernel not applicable to these arguments");
+    }
+}
+
+int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
+                       const uint32_t *d_variant_idx, uint32_t n_variants,
+                       const void *d_prefix_blob, const uint64_t *d_prefix_off,
+                       const uint64_t *d_line_off, uint64_t max_prefix_bytes,
+                       void *d_out, uint32_t flags)
+{
+    (void)flags;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    EmitArgs a;
+    rc = fill_args(ctx, a, d_records, record_stride, d_variant_idx, n_variants, d_out);
+    if (rc) return rc;
+    if (n_variants == 0) return PGENHIP_OK;
+    if (!d_prefix_off || !d_line_off) return fail(PGENHIP_ERR_BAD_ARG, "offset arrays are NULL");
+    if (max_prefix_bytes && !d_prefix_blob) return fail(PGENHIP_ERR_BAD_ARG, "d_prefix_blob is NULL");
+    a.prefix_blob = static_cast<const uint8_t *>(d_prefix_blob);
+    a.prefix_off = d_prefix_off;
+    a.line_off = d_line_off;
+    a.max_line_bytes = max_prefix_bytes + 4ull * ctx->kept_count + 1ull;
+    HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+    return PGENHIP_OK;
+}
+
+int pgenhip_wait(pgenhip_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PGENHIP_OK;
+}
+
+int pgenhip_timer_start(pgenhip_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    return PGENHIP_OK;
+}
+
+int pgenhip_timer_stop(pgenhip_ctx *ctx, float *elapsed_ms)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!elapsed_ms) return fail(PGENHIP_ERR_BAD_ARG, "elapsed_ms is NULL");
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+    return PGENHIP_OK;
+}
+
+int pgenhip_device_malloc(pgenhip_ctx *ctx, void **d_ptr, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_ptr) return fail(PGENHIP_ERR_BAD_ARG, "d_ptr is NULL");
+    *d_ptr = nullptr;
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return PGENHIP_OK;
+}
+
+int pgenhip_device_free(pgenhip_ctx *ctx, void *d_ptr)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return PGENHIP_OK;
+}
+
+int pgenhip_host_malloc_pinned(pgenhip_ctx *ctx, void **h_ptr, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!h_ptr) return fail(PGENHIP_ERR_BAD_ARG, "h_ptr is NULL");
+    *h_ptr = nullptr;
+    HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return PGENHIP_OK;
+}
+
+int pgenhip_host_free_pinned(pgenhip_ctx *ctx, void *h_ptr)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
+    return PGENHIP_OK;
+}
+
+int pgenhip_memcpy_h2d(pgenhip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (bytes && (!d_dst || !h_src)) return fail(PGENHIP_ERR_BAD_ARG, "NULL pointer");
+    if (bytes) HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PGENHIP_OK;
+}
+
+int pgenhip_memcpy_d2h(pgenhip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (bytes && (!h_dst || !d_src)) return fail(PGENHIP_ERR_BAD_ARG, "NULL pointer");
+    if (bytes) HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return PGENHIP_OK;
+}
+
+int pgenhip_synth_records(pgenhip_ctx *ctx, void *d_dst, uint64_t record_stride,
+                          uint64_t first_variant, uint32_t n_variants, uint64_t seed, uint32_t flags)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n_variants && ctx->record_size && !d_dst) return fail(PGENHIP_ERR_BAD_ARG, "d_dst is NULL");
+    if (n_variants > 1 && record_stride < ctx->record_size) return fail(PGENHIP_ERR_BAD_ARG, "record_stride < record size");
+    HIP_TRY(launch_synth_records(static_cast<uint8_t *>(d_dst), record_stride, ctx->sample_count, first_variant,
+                                 n_variants, seed, (flags & PGENHIP_SYNTH_DIRTY_PAD) != 0, ctx->num_cus, ctx->stream));
+    return PGENHIP_OK;
+}
+
+}  // extern "C"

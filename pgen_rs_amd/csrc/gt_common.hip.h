@@ -1,0 +1,52 @@
+// gt_common.hip.h — device helpers shared by the GT decode/emit kernels (gfx950 only).
+//
+// Reference semantics (teoremma/pgen-rs, src/pfile.rs):
+//   :172-175  code(s) = (record[s/4] >> ((s%4)*2)) & 0b11         (LSB-first 2-bit hard calls)
+//   :177-183  00 -> "0/0", 01 -> "0/1", 10 -> "1/1", 11 -> "./."
+//   :186-190  each kept sample emits '\t' + the 3 GT bytes; the row ends with '\n'
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pgenhip {
+
+// One genotype = one little-endian dword of text:
+//   "\t0/0" = 09 30 2F 30, "\t0/1" = 09 30 2F 31, "\t1/1" = 09 31 2F 31, "\t./." = 09 2E 2F 2E.
+// Bytes 0 and 2 are constant; byte 1 is "001."[code], byte 3 is "011."[code].
+// v_perm_b32 picks both from two 4-byte tables with one selector (selector values 0-3 = bytes of
+// the second operand, 4-7 = bytes of the first, 0x0C = constant 0x00), so a genotype costs
+// v_mad_u32_u24 + v_perm_b32 + v_or_b32.
+__device__ __forceinline__ uint32_t gt_text(uint32_t code)
+{
+    constexpr uint32_t kTabA = 0x2E313030u;  // '0','0','1','.'  (allele 1 char by code)
+    constexpr uint32_t kTabB = 0x2E313130u;  // '0','1','1','.'  (allele 2 char by code)
+    uint32_t sel = 0x000C040Cu + code * 0x01000100u;
+    return __builtin_amdgcn_perm(kTabA, kTabB, sel) | 0x002F0009u;
+}
+
+// Funnel: bytes [shift, shift+4) of the 8-byte little-endian pair {lo, hi}.
+__device__ __forceinline__ uint32_t funnel_bytes(uint32_t lo, uint32_t hi, uint32_t shift)
+{
+    return __builtin_amdgcn_alignbyte(hi, lo, shift);
+}
+
+// single text byte of the GT segment at segment offset p (0 <= p < 4K): used only on the
+// per-byte edge path (row heads/tails, prefix seams)
+__device__ __forceinline__ uint32_t gt_text_byte(uint32_t code, uint32_t byte_in_gt)
+{
+    return (gt_text(code) >> (8u * byte_in_gt)) & 0xFFu;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct alignas(16) u32x4 {
+    uint32_t x, y, z, w;
+};
+
+}  // namespace pgenhip

@@ -1,0 +1,19 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO_ROOT = Path(__file__).resolve().parent.parent
+# tests may use the oracle (test infrastructure); the product package never does
+for p in (str(REPO_ROOT), str(REPO_ROOT / "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir() -> Path:
+    return REPO_ROOT / "tests" / "golden"
