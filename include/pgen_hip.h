@@ -131,8 +131,7 @@ int pgenhip_memcpy_d2h(pgenhip_ctx *ctx, void *h_dst, const void *d_src, size_t 
 /* ---- synthetic records generated on the device --------- */
 #define PGENHIP_SYNTH_DIRTY_PAD 1u
 /* record bytes of variant v = LE words splitmix64(seed + (v << 20) + word_idx), truncated to R;
- * pad bits of the last byte zeroed unless PGENHIP_SYNTH_DIRTY_PAD.  Bit-exact twin of the
- * oracle's pgo_synth_records. */
+ * pad bits of the last byte zeroed unless PGENHIP_SYNTH_DIRTY_PAD (the tests hold a CPU twin). */
 int pgenhip_synth_records(pgenhip_ctx *ctx, void *d_dst, uint64_t record_stride,
                           uint64_t first_variant, uint32_t n_variants,
                           uint64_t seed, uint32_t flags);

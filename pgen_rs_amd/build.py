@@ -1,7 +1,9 @@
 """Builds the native pieces in-tree (so they travel to the GPU box with the snapshot).
 
 * ``pgen_rs_amd/libpgen_hip.so`` — HIP kernels + C ABI, ``hipcc --offload-arch=gfx950``.
-* ``oracle/libpgen_oracle.so``   — the CPU oracle (test infrastructure), ``gcc``.
+
+(The CPU oracle under ``oracle/`` is test infrastructure and is built by
+``__graft_entry__.build()`` / its own Makefile, not from here.)
 
 hipcc cross-compiles for gfx950 without a GPU present.  Re-builds only when a source is newer
 than its target.
@@ -18,8 +20,6 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 HIP_LIB = PKG_DIR / "libpgen_hip.so"
-ORACLE_DIR = REPO_ROOT / "oracle"
-ORACLE_LIB = ORACLE_DIR / "libpgen_oracle.so"
 
 HIP_SOURCES = ["capi.hip", "gt_rows.hip"]
 HIPCC_FLAGS = [
@@ -70,18 +70,10 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
     return HIP_LIB
 
 
-def build_oracle(force: bool = False) -> Path:
-    deps = [ORACLE_DIR / "pgen_oracle.c", ORACLE_DIR / "pgen_oracle.h"]
-    if force or _stale(ORACLE_LIB, deps):
-        _run(["make", "-C", str(ORACLE_DIR), "libpgen_oracle.so"], REPO_ROOT)
-    return ORACLE_LIB
-
-
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip(force=force, verbose=verbose)
-    build_oracle(force=force)
 
 
 if __name__ == "__main__":
     build_all(force="--force" in sys.argv, verbose=True)
-    print("built", HIP_LIB, "and", ORACLE_LIB)
+    print("built", HIP_LIB)

@@ -49,4 +49,35 @@ struct alignas(16) u32x4 {
     uint32_t x, y, z, w;
 };
 
+// 16 bytes of one row's all-samples GT text starting at segment offset q (src/pfile.rs:171-187
+// for samples floor(q/4) .. floor(q/4)+4).  Bytes whose segment offset p = q+i lies in
+// [0, 4N) are exact; others (p < 0 when MAYBE_NEG, or p >= 4N) are don't-care filler.
+// Five consecutive samples = 10 bits at bit 2*k0 of the record = bytes b0 and b0+1; the text
+// dwords are funnel-shifted by the phase q & 3 so the caller can store to a 16-B-aligned address.
+template <bool MAYBE_NEG>
+__device__ __forceinline__ u32x4 gt_text16(const uint8_t *__restrict__ rec, int64_t q, uint32_t last_rec_byte)
+{
+    const int32_t k0 = (int32_t)(q >> 2);  // floor(q/4); q < 2^33
+    const uint32_t sh = (uint32_t)q & 3u;
+    const int32_t b0 = k0 >> 2;            // floor(k0/4) >= -1
+    uint32_t lo;
+    if (MAYBE_NEG)
+        lo = b0 >= 0 ? (uint32_t)rec[b0] : 0u;
+    else
+        lo = (uint32_t)rec[b0];
+    const uint32_t hi = (uint32_t)rec[min((uint32_t)(b0 + 1), last_rec_byte)];
+    const uint32_t w = (lo | (hi << 8)) >> (((uint32_t)k0 & 3u) * 2u);
+    const uint32_t t0 = gt_text(w & 3u);
+    const uint32_t t1 = gt_text((w >> 2) & 3u);
+    const uint32_t t2 = gt_text((w >> 4) & 3u);
+    const uint32_t t3 = gt_text((w >> 6) & 3u);
+    const uint32_t t4 = gt_text((w >> 8) & 3u);
+    u32x4 v;
+    v.x = funnel_bytes(t0, t1, sh);
+    v.y = funnel_bytes(t1, t2, sh);
+    v.z = funnel_bytes(t2, t3, sh);
+    v.w = funnel_bytes(t3, t4, sh);
+    return v;
+}
+
 }  // namespace pgenhip

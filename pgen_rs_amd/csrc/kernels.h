@@ -27,7 +27,7 @@ struct EmitArgs {
 // General row-tiled kernel: any alignment, any strides, list gather for kept subsets.
 hipError_t launch_gt_rows(const EmitArgs &a, int num_cus, hipStream_t stream);
 
-// Deterministic synthetic records (twin of oracle pgo_synth_records).
+// Deterministic synthetic records (SURVEY.md §8d counter-based generator).
 hipError_t launch_synth_records(uint8_t *dst, uint64_t record_stride, uint32_t sample_count,
                                 uint64_t first_variant, uint32_t n_variants, uint64_t seed,
                                 bool dirty_pad, int num_cus, hipStream_t stream);

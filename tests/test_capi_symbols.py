@@ -1,0 +1,78 @@
+"""CPU leg: libpgen_hip.so loads, exports every symbol include/pgen_hip.h declares, its pure
+host functions agree with the oracle, and it refuses to run without a device (no fallback)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+import pgen_oracle as oracle
+import pgen_rs_amd
+from pgen_rs_amd import _capi
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (REPO / "include" / "pgen_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pgenhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_binding_expects():
+    assert declared_symbols() == sorted(_capi.PROTOTYPES.keys())
+
+
+@pytest.mark.parametrize("sym", declared_symbols())
+def test_symbol_exported(sym):
+    handle = C.CDLL(str(_capi.LIB_PATH))
+    assert getattr(handle, sym) is not None
+
+
+def test_abi_version():
+    assert _capi.lib.pgenhip_abi_version() == 1
+
+
+def test_record_size_matches_oracle():
+    for n in list(range(0, 130)) + [2504, 500000, 300, 2**31 - 1]:
+        assert pgen_rs_amd.variant_record_size(n) == oracle.variant_record_size(n)
+
+
+def test_record_offset_is_u64_exact():
+    for v, r in [(0, 626), (17783, 626), (34359, 125000), (34360, 125000), (999_999, 125000)]:
+        assert pgen_rs_amd.record_offset(v, r) == oracle.record_offset_exact(v, r) == 12 + v * r
+
+
+def test_parse_header_statuses():
+    good = bytes([0x6C, 0x1B, 0x02]) + (17784).to_bytes(4, "little") + (2504).to_bytes(4, "little") + b"\x40"
+    assert pgen_rs_amd.parse_header(good) == (17784, 2504)
+    for bad, status in [
+        (b"\x6c\x1c" + good[2:], _capi.ERR_BAD_MAGIC),
+        (good[:2] + b"\x10" + good[3:], _capi.ERR_BAD_MODE),
+        (good[:11] + b"\x00", _capi.ERR_BAD_FLAGS),
+    ]:
+        with pytest.raises(pgen_rs_amd.PgenHipError) as ei:
+            pgen_rs_amd.parse_header(bad)
+        assert ei.value.status == status
+
+
+def test_strerror_covers_all_statuses():
+    for s in range(0, -11, -1):
+        assert _capi.lib.pgenhip_strerror(s) not in (None, b"unknown status")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")
+def test_no_device_means_loud_failure_not_fallback():
+    ctx = C.c_void_p()
+    rc = _capi.lib.pgenhip_create(C.byref(ctx), 0, 100, None, 0, 0)
+    assert rc == _capi.ERR_NO_DEVICE
+    assert not ctx.value
+
+
+def test_product_package_never_touches_oracle():
+    # the product path must not import/link/execute anything under oracle/
+    for p in list((REPO / "pgen_rs_amd").rglob("*.py")) + list((REPO / "pgen_rs_amd").rglob("*.hip")) + \
+            list((REPO / "pgen_rs_amd").rglob("*.cpp")) + list((REPO / "pgen_rs_amd").rglob("*.h")):
+        text = p.read_text()
+        assert "pgen_oracle" not in text and "pgo_" not in text, p

@@ -1,0 +1,271 @@
+"""GPU leg: the gfx950 kernels, called through the C ABI, against the CPU oracle and the
+committed golden vectors.  Bit-exact (byte/integer work): every comparison is equality of bytes.
+
+Edge cases follow SURVEY.md §4: N % 4 in {0,1,2,3}, N < 64, N not a multiple of 64/256/512,
+K = 0 / 1 / N, sparse/dense/clustered keep lists, dirty pad bits, V = 1, gapped variant lists,
+unaligned output pointers, padded strides (gap bytes must stay untouched).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import pgen_oracle as oracle
+import pgen_rs_amd
+from helpers import case_names, load_case, sha_table
+from pgen_rs_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+SENTINEL = 0xA5
+
+
+def kernels_for(subset: bool, dense: bool):
+    ks = [_capi.KERNEL_AUTO, _capi.KERNEL_ROWS]
+    if not subset and dense:
+        ks.append(_capi.KERNEL_FLAT)
+    if subset:
+        ks.append(_capi.KERNEL_SCAN)
+    return ks
+
+
+def run_engine(recs_np, v, n, kept=None, kernel=_capi.KERNEL_AUTO, record_stride=None, out_stride=None,
+               variant_idx=None, out_offset=0, records_offset=0):
+    """Runs the HIP path; returns the whole output buffer (sentinel-filled where untouched)."""
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        k = eng.kept_count
+        if out_stride is None:
+            out_stride = 4 * k + 1
+        rec_t = torch.from_numpy(np.ascontiguousarray(recs_np)).to(DEV)
+        total = out_offset + max(v, 1) * out_stride + 64
+        out = torch.full((total,), SENTINEL, dtype=torch.uint8, device=DEV)
+        vidx_t = None
+        if variant_idx is not None:
+            vidx_t = torch.tensor(np.asarray(variant_idx, dtype=np.int64), dtype=torch.int32, device=DEV)
+        eng.decode_emit(rec_t, v, record_stride=record_stride, variant_idx=vidx_t, out=out, out_stride=out_stride,
+                        kernel=kernel, out_offset=out_offset, records_offset=records_offset)
+        eng.wait()
+        return out.cpu().numpy(), k
+
+
+def expect_buffer(want_rows, v, k, out_stride, out_offset, total):
+    buf = np.full(total, SENTINEL, dtype=np.uint8)
+    row = 4 * k + 1
+    for j in range(v):
+        buf[out_offset + j * out_stride : out_offset + j * out_stride + row] = want_rows[j]
+    return buf
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_golden_cases(name):
+    v, n, recs, kept, gt = load_case(name)
+    for kern in kernels_for(kept is not None, True):
+        got, k = run_engine(recs.reshape(-1), v, n, kept=kept, kernel=kern)
+        assert bytes(got[: gt.size]) == bytes(gt), f"kernel {kern}"
+        assert (got[gt.size :] == SENTINEL).all(), f"kernel {kern} wrote past the end"
+
+
+@pytest.mark.parametrize("name", sorted(sha_table().keys()))
+def test_golden_sha_with_device_synth(name):
+    spec = sha_table()[name]
+    n, v = spec["sample_count"], spec["n_variants"]
+    kept = oracle.synth_keep(n, spec["keep_seed"], spec["keep_modulus"]) if spec["keep_modulus"] else None
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        recs = eng.synth_records(v, first_variant=spec["first_variant"], seed=spec["seed"], dirty_pad=spec["dirty_pad"])
+        eng.wait()
+        assert hashlib.sha256(recs.cpu().numpy().tobytes()).hexdigest() == spec["records_sha256"]
+        for kern in kernels_for(kept is not None, True):
+            out = eng.decode_emit(recs, v, kernel=kern)
+            eng.wait()
+            assert out.numel() == spec["gt_bytes"]
+            assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == spec["gt_sha256"], f"kernel {kern}"
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 7, 15, 16, 17, 63, 64, 65, 66, 67, 255, 256, 257, 511, 513, 1023, 2504, 4099, 16385])
+def test_all_samples_vs_oracle(n):
+    rng = np.random.default_rng(n + 1)
+    v = 11
+    r = oracle.variant_record_size(n)
+    recs = rng.integers(0, 256, size=max(v * r, 1), dtype=np.uint8)  # dirty pad bits included
+    want = oracle.decode_emit(recs, v, n).reshape(v, -1)
+    for kern in kernels_for(False, True):
+        got, k = run_engine(recs, v, n, kernel=kern)
+        assert k == n
+        exp = expect_buffer(want, v, n, 4 * n + 1, 0, got.size)
+        assert (got == exp).all(), f"n={n} kernel {kern}"
+
+
+@pytest.mark.parametrize("out_offset", range(0, 17))
+def test_unaligned_output_pointer(out_offset):
+    rng = np.random.default_rng(100 + out_offset)
+    n, v = 131, 6
+    r = oracle.variant_record_size(n)
+    recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
+    want = oracle.decode_emit(recs, v, n).reshape(v, -1)
+    for kern in kernels_for(False, True):
+        got, _ = run_engine(recs, v, n, kernel=kern, out_offset=out_offset)
+        exp = expect_buffer(want, v, n, 4 * n + 1, out_offset, got.size)
+        assert (got == exp).all(), f"kernel {kern}"
+
+
+@pytest.mark.parametrize("pad", [1, 2, 3, 5, 15, 16, 17, 127])
+def test_padded_strides_leave_gaps_untouched(pad):
+    rng = np.random.default_rng(200 + pad)
+    n, v = 203, 7
+    r = oracle.variant_record_size(n)
+    rstride = r + pad
+    recs = rng.integers(0, 256, size=v * rstride + 3, dtype=np.uint8)
+    dense = np.concatenate([recs[3 + i * rstride : 3 + i * rstride + r] for i in range(v)])
+    want = oracle.decode_emit(dense, v, n).reshape(v, -1)
+    ostride = 4 * n + 1 + pad
+    got, _ = run_engine(recs, v, n, record_stride=rstride, out_stride=ostride, records_offset=3)
+    exp = expect_buffer(want, v, n, ostride, 0, got.size)
+    assert (got == exp).all()
+
+
+def test_variant_index_gather():
+    rng = np.random.default_rng(7)
+    n, vfile = 1001, 50
+    r = oracle.variant_record_size(n)
+    recs = rng.integers(0, 256, size=vfile * r, dtype=np.uint8)
+    vidx = [49, 0, 7, 8, 9, 30, 30, 2]
+    want = oracle.decode_emit(recs, len(vidx), n, variant_idx=vidx).reshape(len(vidx), -1)
+    got, _ = run_engine(recs, len(vidx), n, variant_idx=vidx)
+    exp = expect_buffer(want, len(vidx), n, 4 * n + 1, 0, got.size)
+    assert (got == exp).all()
+
+
+def keep_lists(n, rng):
+    yield "k0", np.array([], dtype=np.uint32)
+    yield "first", np.array([0], dtype=np.uint32)
+    yield "last", np.array([n - 1], dtype=np.uint32)
+    yield "all_as_list", np.arange(n, dtype=np.uint32)
+    yield "every2", np.arange(0, n, 2, dtype=np.uint32)
+    yield "every3_off1", np.arange(1, n, 3, dtype=np.uint32)
+    yield "cluster", np.arange(n // 3, min(n, n // 3 + 70), dtype=np.uint32)
+    yield "sparse1pct", np.sort(rng.choice(n, size=max(1, n // 100), replace=False)).astype(np.uint32)
+    yield "dense_holes", np.setdiff1d(np.arange(n), rng.choice(n, size=max(1, n // 50), replace=False)).astype(np.uint32)
+    yield "two_ends", np.array([0, n - 1], dtype=np.uint32) if n > 1 else np.array([0], dtype=np.uint32)
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 130, 257, 1000, 2504, 4097, 20011])
+def test_kept_subsets_vs_oracle(n):
+    rng = np.random.default_rng(300 + n)
+    v = 5
+    r = oracle.variant_record_size(n)
+    recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
+    for label, kept in keep_lists(n, rng):
+        want = oracle.decode_emit(recs, v, n, kept_idx=kept).reshape(v, -1)
+        for kern in kernels_for(True, True):
+            got, k = run_engine(recs, v, n, kept=kept, kernel=kern)
+            assert k == kept.size
+            exp = expect_buffer(want, v, k, 4 * k + 1, 0, got.size)
+            assert (got == exp).all(), f"n={n} keep={label} kernel {kern}"
+
+
+def test_subset_with_strides_offsets_and_gather():
+    rng = np.random.default_rng(9)
+    n, vfile = 777, 20
+    r = oracle.variant_record_size(n)
+    rstride = r + 9
+    recs = rng.integers(0, 256, size=vfile * rstride + 5, dtype=np.uint8)
+    kept = np.arange(2, n, 5, dtype=np.uint32)
+    vidx = [3, 19, 4, 0]
+    dense = np.concatenate([recs[5 + i * rstride : 5 + i * rstride + r] for i in range(vfile)])
+    want = oracle.decode_emit(dense, len(vidx), n, kept_idx=kept, variant_idx=vidx).reshape(len(vidx), -1)
+    k = kept.size
+    for kern in kernels_for(True, False):
+        got, _ = run_engine(recs, len(vidx), n, kept=kept, kernel=kern, record_stride=rstride, out_stride=4 * k + 1 + 6,
+                            variant_idx=vidx, out_offset=3, records_offset=5)
+        exp = expect_buffer(want, len(vidx), k, 4 * k + 1 + 6, 3, got.size)
+        assert (got == exp).all(), f"kernel {kern}"
+
+
+def test_single_variant_and_zero_variants():
+    n = 90
+    recs = np.arange(oracle.variant_record_size(n), dtype=np.uint8)
+    want = oracle.decode_emit(recs, 1, n).reshape(1, -1)
+    got, _ = run_engine(recs, 1, n)
+    assert (got == expect_buffer(want, 1, n, 4 * n + 1, 0, got.size)).all()
+    got, _ = run_engine(recs, 0, n)
+    assert (got == SENTINEL).all()
+
+
+@pytest.mark.parametrize("n,kept_mod", [(19, None), (2504, None), (2504, 7), (5003, 100)])
+def test_emit_lines_vs_oracle(n, kept_mod):
+    rng = np.random.default_rng(400 + n)
+    v = 23
+    r = oracle.variant_record_size(n)
+    recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
+    kept = oracle.synth_keep(n, modulus=kept_mod) if kept_mod else None
+    k = n if kept is None else kept.size
+    prefixes = []
+    for i in range(v):
+        info = "x" * int(rng.integers(0, 200))
+        prefixes.append(f"22\t{16050000 + 7 * i}\tsnp{i}\tA\tG\t100\tPASS\t{info}\tGT".encode())
+    blob = np.frombuffer(b"".join(prefixes), dtype=np.uint8)
+    poff = np.cumsum([0] + [len(p) for p in prefixes]).astype(np.int64)
+    loff = np.cumsum([0] + [len(p) + 4 * k + 1 for p in prefixes]).astype(np.int64)
+    want = oracle.emit_lines(recs, v, n, blob, poff.astype(np.uint64), loff.astype(np.uint64), kept_idx=kept)
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        out = torch.full((int(loff[-1]) + 32,), SENTINEL, dtype=torch.uint8, device=DEV)
+        eng.emit_lines(torch.from_numpy(recs).to(DEV), v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV),
+                       torch.from_numpy(loff).to(DEV), max(len(p) for p in prefixes), out)
+        eng.wait()
+        got = out.cpu().numpy()
+    assert bytes(got[: want.size]) == want.tobytes()
+    assert (got[want.size :] == SENTINEL).all()
+
+
+def test_device_synth_matches_oracle_twin():
+    for n, v, first, stride_pad, dirty in [(2504, 33, 0, 0, False), (10007, 9, 123, 3, True), (5, 4, 2**31, 0, False), (500000, 2, 999_999, 0, False)]:
+        r = oracle.variant_record_size(n)
+        with pgen_rs_amd.GtEngine(n, device=0) as eng:
+            t = eng.synth_records(v, first_variant=first, record_stride=r + stride_pad, dirty_pad=dirty)
+            eng.wait()
+            got = t.cpu().numpy()
+        want = oracle.synth_records(n, v, first, record_stride=r + stride_pad, dirty_pad=dirty)
+        got2 = got[: want.size].reshape(v, r + stride_pad)[:, :r]
+        assert (got2 == want.reshape(v, r + stride_pad)[:, :r]).all()
+
+
+def test_bad_arguments_are_status_codes_not_crashes():
+    with pytest.raises(pgen_rs_amd.PgenHipError) as ei:
+        pgen_rs_amd.GtEngine(10, kept_idx=[3, 10])
+    assert ei.value.status == _capi.ERR_INDEX_RANGE
+    with pytest.raises(pgen_rs_amd.PgenHipError) as ei:
+        pgen_rs_amd.GtEngine(10, kept_idx=[3, 3])
+    assert ei.value.status == _capi.ERR_BAD_ARG
+    with pytest.raises(pgen_rs_amd.PgenHipError) as ei:
+        pgen_rs_amd.GtEngine(10, device=99)
+    assert ei.value.status == _capi.ERR_NO_DEVICE
+    with pgen_rs_amd.GtEngine(10) as eng:
+        recs = torch.zeros(30, dtype=torch.uint8, device=DEV)
+        out = torch.zeros(1000, dtype=torch.uint8, device=DEV)
+        with pytest.raises(pgen_rs_amd.PgenHipError) as ei:
+            eng.decode_emit(recs, 3, out=out, out_stride=40)  # < 4K+1
+        assert ei.value.status == _capi.ERR_BAD_ARG
+
+
+def test_large_shape_properties_config3_rows():
+    """BASELINE config 3 row geometry (N = 500 000) on a few rows: size-independent properties —
+    every 4th byte is TAB, rows end in LF, slash column, and the allele columns re-encode to the
+    input codes (decode -> re-encode round trip), plus equality with the oracle on those rows."""
+    n, v, first = 500_000, 6, 34_357  # straddles the reference's u32 wrap index 34 360 (F5)
+    with pgen_rs_amd.GtEngine(n, device=0) as eng:
+        recs = eng.synth_records(v, first_variant=first)
+        out = eng.decode_emit(recs, v)
+        eng.wait()
+        rows = out.cpu().numpy().reshape(v, 4 * n + 1)
+        host = recs.cpu().numpy()
+    assert (rows[:, -1] == ord("\n")).all()
+    body = rows[:, :-1].reshape(v, n, 4)
+    assert (body[:, :, 0] == 9).all() and (body[:, :, 2] == ord("/")).all()
+    a, b = body[:, :, 1], body[:, :, 3]
+    code = np.where(a == ord("."), 3, (a - ord("0")) + (b - ord("0"))).astype(np.uint8)
+    shifts = np.array([0, 2, 4, 6], dtype=np.uint8)
+    want_code = ((host.reshape(v, -1)[:, :, None] >> shifts) & 3).reshape(v, -1)[:, :n]
+    assert (code == want_code).all()
+    assert rows.tobytes() == oracle.decode_emit(host, v, n).tobytes()
