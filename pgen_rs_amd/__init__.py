@@ -10,6 +10,7 @@ from ._capi import (  # noqa: F401
     KERNEL_FLAT,
     KERNEL_ROWS,
     KERNEL_SCAN,
+    KERNEL_WIDE,
     PgenHipError,
 )
 from .engine import (  # noqa: F401
@@ -31,4 +32,5 @@ __all__ = [
     "KERNEL_ROWS",
     "KERNEL_FLAT",
     "KERNEL_SCAN",
+    "KERNEL_WIDE",
 ]

@@ -34,6 +34,7 @@ KERNEL_AUTO = 0
 KERNEL_ROWS = 1
 KERNEL_FLAT = 2
 KERNEL_SCAN = 3
+KERNEL_WIDE = 4
 SYNTH_DIRTY_PAD = 1
 
 u8p = C.POINTER(C.c_uint8)

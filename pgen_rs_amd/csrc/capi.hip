@@ -7,6 +7,7 @@
 
 #include <new>
 #include <string>
+#include <vector>
 
 #include "kernels.h"
 
@@ -20,6 +21,8 @@ struct pgenhip_ctx {
     uint32_t kept_count = 0;
     bool subset = false;
     uint32_t *d_kept = nullptr;
+    uint64_t *d_keep_words = nullptr;  // scan kernel: keep bitmap, zero-padded to whole segments
+    uint32_t *d_seg_rank = nullptr;    // scan kernel: kept samples before each segment
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr;
@@ -164,6 +167,21 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
             if (kept_count) {
                 if ((e = hipMemcpy(ctx->d_kept, kept_idx, (size_t)kept_count * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(kept_idx)"); break; }
             }
+            // the same selection as a bitmap + per-segment ranks (what the scan kernel stages in LDS)
+            const uint32_t n_seg = (sample_count + kScanSegmentSamples - 1u) / kScanSegmentSamples;
+            const uint32_t n_seg_eff = n_seg ? n_seg : 1u;
+            const size_t words_per_seg = kScanSegmentSamples / 64u;
+            std::vector<uint64_t> words((size_t)n_seg_eff * words_per_seg, 0ull);
+            std::vector<uint32_t> seg_rank((size_t)n_seg_eff + 1u, 0u);
+            for (uint32_t k = 0; k < kept_count; k++) {
+                words[kept_idx[k] >> 6] |= 1ull << (kept_idx[k] & 63u);
+                seg_rank[(size_t)(kept_idx[k] / kScanSegmentSamples) + 1u]++;
+            }
+            for (uint32_t g = 0; g < n_seg_eff; g++) seg_rank[g + 1u] += seg_rank[g];
+            if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_keep_words), words.size() * sizeof(uint64_t))) != hipSuccess) { rc = fail_hip(e, "hipMalloc(keep bitmap)"); break; }
+            if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_seg_rank), seg_rank.size() * sizeof(uint32_t))) != hipSuccess) { rc = fail_hip(e, "hipMalloc(segment ranks)"); break; }
+            if ((e = hipMemcpy(ctx->d_keep_words, words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(keep bitmap)"); break; }
+            if ((e = hipMemcpy(ctx->d_seg_rank, seg_rank.data(), seg_rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(segment ranks)"); break; }
         }
     } while (0);
     if (rc != PGENHIP_OK) {
@@ -182,6 +200,8 @@ int pgenhip_destroy(pgenhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->d_kept) (void)hipFree(ctx->d_kept);
+    if (ctx->d_keep_words) (void)hipFree(ctx->d_keep_words);
+    if (ctx->d_seg_rank) (void)hipFree(ctx->d_seg_rank);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -241,8 +261,32 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
     const uint32_t which = flags & PGENHIP_KERNEL_MASK;
     switch (which) {
         case PGENHIP_KERNEL_AUTO:
+            if (ctx->subset) {
+                ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank};
+                HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
+            } else if (gt_wide_applicable(a))
+                HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+            else if (gt_flat_applicable(a))
+                HIP_TRY(launch_gt_flat(a, ctx->num_cus, ctx->stream));
+            else
+                HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
         case PGENHIP_KERNEL_ROWS:
             HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        case PGENHIP_KERNEL_SCAN: {
+            if (!ctx->subset) return fail(PGENHIP_ERR_BAD_ARG, "scan kernel needs a kept-sample list");
+            ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank};
+            HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        }
+        case PGENHIP_KERNEL_WIDE:
+            if (!gt_wide_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "wide kernel needs all samples kept, N >= 1024 and out_stride == 4N+1");
+            HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        case PGENHIP_KERNEL_FLAT:
+            if (!gt_flat_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "flat kernel needs all samples kept and out_stride == 4N+1");
+            HIP_TRY(launch_gt_flat(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         default:
             return fail(PGENHIP_ERR_BAD_ARG, "requested kernel not applicable to these arguments");

@@ -49,24 +49,37 @@ struct alignas(16) u32x4 {
     uint32_t x, y, z, w;
 };
 
-// 16 bytes of one row's all-samples GT text starting at segment offset q (src/pfile.rs:171-187
-// for samples floor(q/4) .. floor(q/4)+4).  Bytes whose segment offset p = q+i lies in
-// [0, 4N) are exact; others (p < 0 when MAYBE_NEG, or p >= 4N) are don't-care filler.
-// Five consecutive samples = 10 bits at bit 2*k0 of the record = bytes b0 and b0+1; the text
-// dwords are funnel-shifted by the phase q & 3 so the caller can store to a 16-B-aligned address.
-template <bool MAYBE_NEG>
-__device__ __forceinline__ u32x4 gt_text16(const uint8_t *__restrict__ rec, int64_t q, uint32_t last_rec_byte)
+// ---- all-samples text from a 16-bit record window ---------------------------------------------
+// 16 bytes of one row's GT text starting at segment offset q (q >= -15) cover samples
+// k0 = floor(q/4) .. k0+4 = 10 bits at bit 2*k0 of the record = record bytes b0 = floor(q/16)
+// and b0+1.  load_window fetches those two bytes (out-of-record bytes, needed only for
+// don't-care positions, are clamped/zeroed), gt_text16_from_window turns them into the 16 text
+// bytes, funnel-shifted by the phase q & 3 so the caller can store to a 16-B-aligned address.
+// Bytes whose segment offset q+i lies in [0, 4N) are exact; the others are filler.
+//
+// LOAD16: one (possibly odd-address) global_load_ushort instead of two byte loads; the address
+// is clamped to [0, R-2] (requires R >= 2) so no byte outside the record is touched.
+template <bool LOAD16>
+__device__ __forceinline__ uint32_t load_window(const uint8_t *__restrict__ rec, int32_t b0, uint32_t last_rec_byte)
 {
-    const int32_t k0 = (int32_t)(q >> 2);  // floor(q/4); q < 2^33
+    if (LOAD16) {
+        const int32_t bb = max(0, min(b0, (int32_t)last_rec_byte - 1));
+        uint16_t h;
+        __builtin_memcpy(&h, rec + bb, 2);
+        const int32_t d = b0 - bb;  // -1, 0 or +1 (more only for don't-care windows)
+        return d < 0 ? ((uint32_t)h << 8) & 0xFFFFu : (uint32_t)h >> (8u * (uint32_t)min(d, 2));
+    } else {
+        const uint32_t lo = b0 >= 0 ? (uint32_t)rec[min((uint32_t)b0, last_rec_byte)] : 0u;
+        const uint32_t hi = (uint32_t)rec[min((uint32_t)(b0 + 1), last_rec_byte)];
+        return lo | (hi << 8);
+    }
+}
+
+__device__ __forceinline__ u32x4 gt_text16_from_window(uint32_t window, int64_t q)
+{
+    const uint32_t k0 = (uint32_t)(q >> 2);  // floor(q/4) mod 2^32; only its low 2 bits matter here
     const uint32_t sh = (uint32_t)q & 3u;
-    const int32_t b0 = k0 >> 2;            // floor(k0/4) >= -1
-    uint32_t lo;
-    if (MAYBE_NEG)
-        lo = b0 >= 0 ? (uint32_t)rec[b0] : 0u;
-    else
-        lo = (uint32_t)rec[b0];
-    const uint32_t hi = (uint32_t)rec[min((uint32_t)(b0 + 1), last_rec_byte)];
-    const uint32_t w = (lo | (hi << 8)) >> (((uint32_t)k0 & 3u) * 2u);
+    const uint32_t w = window >> ((k0 & 3u) * 2u);
     const uint32_t t0 = gt_text(w & 3u);
     const uint32_t t1 = gt_text((w >> 2) & 3u);
     const uint32_t t2 = gt_text((w >> 4) & 3u);

@@ -67,38 +67,29 @@ __global__ __launch_bounds__(kThreads) void gt_rows_kernel(EmitArgs a, uint32_t 
             if (i >= n_chunks) break;
             const uint64_t caddr = (chunk0 + i) << 4;
             const int64_t q = (int64_t)(caddr - gt_addr);  // chunk start relative to the GT segment
-            u32x4 *dst = reinterpret_cast<u32x4 *>((uintptr_t)caddr);
+            u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + (int64_t)(caddr - (uint64_t)(uintptr_t)a.out));  // stays a global pointer
 
             if (q >= 0 && (uint64_t)q + 16ull <= gt_bytes) {
                 // interior chunk: bytes q..q+15 of the GT segment = samples k0..k0+4, phase sh
-                const uint32_t k0 = (uint32_t)((uint64_t)q >> 2);
-                const uint32_t sh = (uint32_t)q & 3u;
-                uint32_t t0, t1, t2, t3, t4;
                 if (!SUBSET) {
-                    // 10 bits starting at bit 2*k0 of the record: bytes b0 and b0+1.  b0+1 can
-                    // lie past the record only when the 5th sample is not needed -> clamp.
-                    const uint32_t b0 = k0 >> 2;
-                    const uint32_t b1 = min(b0 + 1u, last_rec_byte);
-                    const uint32_t w = ((uint32_t)rec[b0] | ((uint32_t)rec[b1] << 8)) >> ((k0 & 3u) * 2u);
-                    t0 = gt_text(w & 3u);
-                    t1 = gt_text((w >> 2) & 3u);
-                    t2 = gt_text((w >> 4) & 3u);
-                    t3 = gt_text((w >> 6) & 3u);
-                    t4 = gt_text((w >> 8) & 3u);
+                    // 10-bit window of samples k0..k0+4 (record bytes q/16 and q/16+1)
+                    *dst = gt_text16_from_window(load_window<false>(rec, (int32_t)(q >> 4), last_rec_byte), q);
                 } else {
+                    const uint32_t k0 = (uint32_t)((uint64_t)q >> 2);
+                    const uint32_t sh = (uint32_t)q & 3u;
                     const uint32_t klast = a.kept_count - 1u;
-                    t0 = gt_text(load_code<true>(rec, a.kept_idx, k0));
-                    t1 = gt_text(load_code<true>(rec, a.kept_idx, k0 + 1u));
-                    t2 = gt_text(load_code<true>(rec, a.kept_idx, k0 + 2u));
-                    t3 = gt_text(load_code<true>(rec, a.kept_idx, k0 + 3u));
-                    t4 = gt_text(load_code<true>(rec, a.kept_idx, min(k0 + 4u, klast)));
+                    const uint32_t t0 = gt_text(load_code<true>(rec, a.kept_idx, k0));
+                    const uint32_t t1 = gt_text(load_code<true>(rec, a.kept_idx, k0 + 1u));
+                    const uint32_t t2 = gt_text(load_code<true>(rec, a.kept_idx, k0 + 2u));
+                    const uint32_t t3 = gt_text(load_code<true>(rec, a.kept_idx, k0 + 3u));
+                    const uint32_t t4 = gt_text(load_code<true>(rec, a.kept_idx, min(k0 + 4u, klast)));
+                    u32x4 v;
+                    v.x = funnel_bytes(t0, t1, sh);
+                    v.y = funnel_bytes(t1, t2, sh);
+                    v.z = funnel_bytes(t2, t3, sh);
+                    v.w = funnel_bytes(t3, t4, sh);
+                    *dst = v;
                 }
-                u32x4 v;
-                v.x = funnel_bytes(t0, t1, sh);
-                v.y = funnel_bytes(t1, t2, sh);
-                v.z = funnel_bytes(t2, t3, sh);
-                v.w = funnel_bytes(t3, t4, sh);
-                *dst = v;
             } else {
                 // edge chunk (row head/tail, prefix bytes, '\n'): one byte at a time
                 uint32_t d[4] = {0u, 0u, 0u, 0u};
@@ -126,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void gt_rows_kernel(EmitArgs a, uint32_t 
                     u32x4 v = {d[0], d[1], d[2], d[3]};
                     *dst = v;
                 } else {
-                    uint8_t *bp = reinterpret_cast<uint8_t *>((uintptr_t)caddr);
+                    uint8_t *bp = reinterpret_cast<uint8_t *>(dst);
 #pragma unroll
                     for (int b = 0; b < 16; b++) {
                         if (valid & (1u << b)) bp[b] = (uint8_t)(d[b >> 2] >> (8 * (b & 3)));

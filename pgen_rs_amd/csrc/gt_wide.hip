@@ -1,0 +1,263 @@
+// gt_wide.hip — dense all-samples kernel with wide, LDS-staged record loads (gfx950 / MI355X).
+//
+// Same contract and output-stream view as gt_flat.hip (K = N, rows packed at 4N+1 bytes; every
+// lane stores one 16-byte-ALIGNED chunk of the launch's output stream), but the 2-bit words are
+// no longer fetched with two byte loads per chunk.  Measured on MI355X (tools/membench): a kernel
+// that pairs each 1-KiB wave store with a 64-byte wave load tops out at ~4.3 TB/s whatever the
+// pipelining depth, while one 1-KiB wide load feeding sixteen 1-KiB stores reaches ~5.3 TB/s —
+// few, large read bursts disturb the HBM write stream far less than many small ones.
+//
+// Work item = (row j, span k): one WAVE owns up to 1024 consecutive chunks (16 KiB of text) that
+// start inside row j.  The wave
+//   1. loads the <= 1026 record bytes behind them with ONE global_load_dwordx4 per lane
+//      (16-B-aligned addresses, 8+ whole 128-B lines per instruction) and parks them in its
+//      private LDS slab (ds_write_b128),
+//   2. then runs 16 store steps: lane reads its 10-bit window (ds_read_u16 at the byte it needs),
+//      expands 5 genotypes to text, funnel-shifts by the row's phase (wave-uniform here) and
+//      issues one global_store_dwordx4 — 1 KiB of contiguous text per wave instruction.
+// The next item's record bytes are requested before the stores of the current one are issued
+// (register double-buffering), so loads stay in flight behind the store stream.
+// The chunk that holds a row's '\n' also holds the head of row j+1: its first bytes come from a
+// direct byte load (one lane per row).  Stream head/tail chunks use masked byte stores.
+#include <stdlib.h>
+
+#include "gt_common.hip.h"
+#include "kernels.h"
+
+namespace pgenhip {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr uint32_t kSpanChunks = 1024;  // chunks per work item: 16 stores x 64 lanes
+constexpr uint32_t kSlabBytes = 1088;   // 66 lanes x 16 B staged at most, rounded to 64
+
+struct WideParams {
+    uint64_t row_bytes;      // S = 4N + 1
+    uint64_t total_bytes;    // T = V * S
+    uint64_t n_items;        // V * spans_per_row
+    uint32_t spans_per_row;
+    uint32_t head;           // out address & 15
+};
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+template <bool HAS_VIDX>
+__device__ __forceinline__ const uint8_t *row_record(const EmitArgs &a, uint64_t r)
+{
+    const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[r] : r;
+    return a.records + src * a.record_stride;
+}
+
+template <bool NT>
+__device__ __forceinline__ void store_chunk(uint8_t *dst, const u32x4 &v)
+{
+    v4u t = {v.x, v.y, v.z, v.w};
+    if (NT)
+        __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(dst));
+    else
+        *reinterpret_cast<v4u *>(dst) = t;
+}
+
+// geometry of one work item (all wave-uniform)
+struct Item {
+    uint64_t g0;          // first chunk (index into the aligned chunk space of the stream)
+    uint32_t cnt;         // chunks in this item (0 = nothing to do)
+    int64_t c_first;      // row-relative byte offset of chunk g0's first byte (>= -15)
+    const uint8_t *rec;   // record of row j
+    const uint8_t *base;  // 16-B-aligned address the staged bytes start at
+    uint32_t n_load;      // 16-byte pieces to stage (<= 66)
+    uint64_t row;         // j
+};
+
+template <bool HAS_VIDX>
+__device__ __forceinline__ Item make_item(const EmitArgs &a, const WideParams &p, uint64_t t)
+{
+    Item it;
+    const uint64_t S = p.row_bytes;
+    const uint64_t j = p.spans_per_row == 1u ? t : t / p.spans_per_row;
+    const uint32_t k = p.spans_per_row == 1u ? 0u : (uint32_t)(t - j * p.spans_per_row);
+    const uint64_t row_start = j * S;
+    // row j owns the chunks whose first byte lies in [j*S, (j+1)*S); row 0 also the head chunk
+    const uint64_t g_first = j == 0 ? 0ull : (row_start + p.head + 15ull) >> 4;
+    const uint64_t g_end = (row_start + S + p.head + 15ull) >> 4;
+    it.row = j;
+    it.g0 = g_first + (uint64_t)k * kSpanChunks;
+    it.cnt = it.g0 < g_end ? (uint32_t)min((uint64_t)kSpanChunks, g_end - it.g0) : 0u;
+    it.c_first = (int64_t)(it.g0 * 16ull) - (int64_t)p.head - (int64_t)row_start;
+    it.rec = row_record<HAS_VIDX>(a, j);
+    const uint32_t last = a.record_size - 1u;
+    const int64_t bf = it.c_first >> 4;  // first record byte needed (-1 for the head chunk)
+    const uint32_t b_first = bf > 0 ? (uint32_t)min(bf, (int64_t)last - 1) : 0u;  // R >= 2
+    const uint32_t b_last = (uint32_t)min(bf + (int64_t)it.cnt, (int64_t)last);  // window hi byte of the last chunk
+    const uint64_t addr_first = (uint64_t)(uintptr_t)(it.rec + b_first);
+    const uint32_t mis = (uint32_t)(addr_first & 15ull);
+    it.base = it.rec + b_first - mis;
+    it.n_load = it.cnt ? (mis + (b_last - b_first)) / 16u + 1u : 0u;
+    return it;
+}
+
+template <bool HAS_VIDX, bool NT>
+__global__ __launch_bounds__(kThreads) void gt_wide_kernel(EmitArgs a, WideParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t slabs[kWaves][kSlabBytes];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR item math
+    uint8_t *const slab = slabs[wave];
+    const uint64_t S = p.row_bytes;
+    const uint64_t gt_bytes = S - 1ull;
+    const uint32_t last = a.record_size - 1u;
+    uint8_t *const chunk0 = a.out - p.head;
+    const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
+
+    uint64_t t = (uint64_t)blockIdx.x * kWaves + wave;
+    if (t >= p.n_items) return;
+
+    Item cur = make_item<HAS_VIDX>(a, p, t);
+    v4u in0 = {0u, 0u, 0u, 0u}, in1 = {0u, 0u, 0u, 0u};
+    if (lane < cur.n_load) in0 = *reinterpret_cast<const v4u *>(cur.base + lane * 16u);
+    if (lane + 64u < cur.n_load) in1 = *reinterpret_cast<const v4u *>(cur.base + (lane + 64u) * 16u);
+
+    for (;;) {
+        // ---- park this item's record bytes in the wave's slab
+        *reinterpret_cast<v4u *>(slab + lane * 16u) = in0;
+        if (lane < 4u) *reinterpret_cast<v4u *>(slab + (lane + 64u) * 16u) = in1;
+
+        // ---- request the next item's bytes before this item's stores go out
+        const uint64_t t_next = t + n_waves;
+        const bool more = t_next < p.n_items;
+        Item nxt = cur;
+        if (more) {
+            nxt = make_item<HAS_VIDX>(a, p, t_next);
+            if (lane < nxt.n_load) in0 = *reinterpret_cast<const v4u *>(nxt.base + lane * 16u);
+            if (lane + 64u < nxt.n_load) in1 = *reinterpret_cast<const v4u *>(nxt.base + (lane + 64u) * 16u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- 16 store steps over the staged bytes
+        const int32_t bf = (int32_t)(cur.c_first >> 4);                 // record byte of chunk 0's window (>= -1)
+        const int32_t delta = (int32_t)(cur.rec - cur.base);            // slab offset of record byte 0
+        const uint32_t phase = (uint32_t)cur.c_first & 15u;             // same for every chunk of the row
+        // chunks 0 .. n_interior-1 lie wholly inside the row's GT text
+        const int64_t room = (int64_t)gt_bytes - 16 - cur.c_first;      // c_first + 16*i + 16 <= gt_bytes
+        const uint32_t n_interior = room < 0 ? 0u : (uint32_t)min((int64_t)cur.cnt, room / 16 + 1);
+        const bool head_chunk = cur.c_first < 0;                        // only (row 0, span 0) with an unaligned out
+#pragma unroll 4
+        for (uint32_t u = 0; u < kSpanChunks / 64u; u++) {
+            const uint32_t i = u * 64u + lane;
+            if (u * 64u >= cur.cnt) break;
+            if (i >= cur.cnt) continue;
+            uint8_t *dst = chunk0 + (cur.g0 + i) * 16ull;
+            const int32_t b0 = bf + (int32_t)i;
+            uint32_t window;
+            {
+                // bytes b0, b0+1 of the record (clamped to the staged range for don't-care positions)
+                const int32_t bb = max(0, min(b0, (int32_t)last - 1));
+                uint16_t h;
+                __builtin_memcpy(&h, slab + bb + delta, 2);
+                const int32_t d = b0 - bb;
+                window = d < 0 ? ((uint32_t)h << 8) & 0xFFFFu : (uint32_t)h >> (8u * (uint32_t)min(d, 2));
+            }
+            if (i < n_interior && !(head_chunk && i == 0u)) {
+                store_chunk<NT>(dst, gt_text16_from_window(window, (int64_t)phase));
+                continue;
+            }
+            // ---- row tail: the chunk holds '\n' at byte nl (and the head of row j+1 behind it)
+            const int64_t c = cur.c_first + 16ll * (int64_t)i;
+            const int64_t o = (int64_t)((cur.g0 + i) * 16ull) - (int64_t)p.head;
+            const uint32_t nl = (uint32_t)((int64_t)gt_bytes - c);  // 0..15 when c >= 0
+            if (c >= 0 && (cur.row + 1ull < a.n_variants || nl == 15u)) {
+                u32x4 x = gt_text16_from_window(window, c);
+                u32x4 y = {0u, 0u, 0u, 0u};
+                if (nl < 15u) {
+                    const int64_t qy = -(int64_t)nl - 1;  // row j+1 starts nl+1 bytes into the chunk
+                    y = gt_text16_from_window(load_window<false>(row_record<HAS_VIDX>(a, cur.row + 1ull), -1, last), qy);
+                }
+                uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+                uint32_t ys[4] = {y.x, y.y, y.z, y.w};
+                uint32_t os[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int32_t nb = (int32_t)nl - 4 * m;  // bytes of dword m taken from x
+                    const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+                    uint32_t v = (xs[m] & mask) | (ys[m] & ~mask);
+                    if (nb >= 0 && nb < 4) v = (v & ~(0xFFu << (8 * nb))) | (0x0Au << (8 * nb));
+                    os[m] = v;
+                }
+                u32x4 v = {os[0], os[1], os[2], os[3]};
+                store_chunk<NT>(dst, v);
+            } else {
+                // first/last chunk of the whole stream: byte-wise with a validity mask
+                uint64_t rr = cur.row;
+                int64_t cc = c;
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    const int64_t ob = o + b;
+                    if (ob >= 0 && (uint64_t)ob < p.total_bytes) {
+                        if (cc >= (int64_t)S) {
+                            cc -= (int64_t)S;
+                            rr++;
+                        }
+                        uint32_t ch;
+                        if ((uint64_t)cc == gt_bytes) {
+                            ch = '\n';
+                        } else {
+                            const uint32_t s = (uint32_t)((uint64_t)cc >> 2);
+                            const uint32_t code = ((uint32_t)row_record<HAS_VIDX>(a, rr)[s >> 2] >> ((s & 3u) * 2u)) & 3u;
+                            ch = gt_text_byte(code, (uint32_t)cc & 3u);
+                        }
+                        dst[b] = (uint8_t)ch;
+                    }
+                    cc++;
+                }
+            }
+        }
+        if (!more) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
+        t = t_next;
+    }
+}
+
+}  // namespace
+
+bool gt_wide_applicable(const EmitArgs &a)
+{
+    // rows of >= 4 KiB keep a wave's span reasonably full; R >= 16 for the clamped window reads
+    return a.kept_idx == nullptr && a.line_off == nullptr && a.sample_count >= 1024u &&
+           (a.n_variants <= 1 || a.out_stride == 4ull * a.kept_count + 1ull);
+}
+
+hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
+{
+    if (a.n_variants == 0) return hipSuccess;
+    WideParams p;
+    p.row_bytes = 4ull * a.kept_count + 1ull;
+    p.total_bytes = (uint64_t)a.n_variants * p.row_bytes;
+    p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 15ull);
+    // a row owns floor(S/16) or ceil(S/16) chunks (one more for row 0 with an unaligned pointer)
+    const uint64_t max_row_chunks = (p.row_bytes + 15ull) / 16ull + 1ull;
+    p.spans_per_row = (uint32_t)((max_row_chunks + kSpanChunks - 1ull) / kSpanChunks);
+    p.n_items = (uint64_t)a.n_variants * p.spans_per_row;
+
+    const char *eb = getenv("PGENHIP_WIDE_BLOCKS_PER_CU");
+    const int blocks_per_cu = eb ? atoi(eb) : (p.spans_per_row == 1u ? 4 : 8);
+    const char *en = getenv("PGENHIP_WIDE_NT");
+    const bool nt = en ? atoi(en) != 0 : false;
+    const uint64_t blocks_needed = (p.n_items + kWaves - 1ull) / kWaves;
+    const uint64_t max_grid = (uint64_t)num_cus * (uint64_t)blocks_per_cu;
+    const uint32_t grid = (uint32_t)(blocks_needed < max_grid ? blocks_needed : max_grid);
+    void (*kern)(EmitArgs, WideParams);
+    if (a.variant_idx)
+        kern = nt ? gt_wide_kernel<true, true> : gt_wide_kernel<true, false>;
+    else
+        kern = nt ? gt_wide_kernel<false, true> : gt_wide_kernel<false, false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, p);
+    return hipGetLastError();
+}
+
+}  // namespace pgenhip

@@ -27,6 +27,25 @@ struct EmitArgs {
 // General row-tiled kernel: any alignment, any strides, list gather for kept subsets.
 hipError_t launch_gt_rows(const EmitArgs &a, int num_cus, hipStream_t stream);
 
+// Dense all-samples stream kernel (K = N, out_stride == 4N+1): every lane owns one aligned
+// 16-byte chunk of the whole launch's output stream.
+bool gt_flat_applicable(const EmitArgs &a);
+hipError_t launch_gt_flat(const EmitArgs &a, int num_cus, hipStream_t stream);
+
+// Same contract as the flat kernel, but a wave stages its span's record bytes with one wide
+// (16 B/lane) load into LDS and then issues 16 coalesced 1-KiB stores (rows >= 4 KiB of text).
+bool gt_wide_applicable(const EmitArgs &a);
+hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream);
+
+// Kept-subset scan kernel: per-context keep bitmap (N bits, zero-padded to whole segments of
+// kScanSegmentSamples) + number of kept samples before each segment.
+constexpr uint32_t kScanSegmentSamples = 16384u;
+struct ScanArgs {
+    const uint64_t *keep_words;  // device; n_segments * (kScanSegmentSamples / 64) words
+    const uint32_t *seg_rank;    // device; n_segments + 1 entries
+};
+hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hipStream_t stream);
+
 // Deterministic synthetic records (SURVEY.md §8d counter-based generator).
 hipError_t launch_synth_records(uint8_t *dst, uint64_t record_stride, uint32_t sample_count,
                                 uint64_t first_variant, uint32_t n_variants, uint64_t seed,

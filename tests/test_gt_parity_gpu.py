@@ -22,10 +22,12 @@ DEV = "cuda:0"
 SENTINEL = 0xA5
 
 
-def kernels_for(subset: bool, dense: bool):
+def kernels_for(subset: bool, dense: bool, n: int = 0):
     ks = [_capi.KERNEL_AUTO, _capi.KERNEL_ROWS]
-    if not subset and dense:
+    if not subset and dense and n >= 8:
         ks.append(_capi.KERNEL_FLAT)
+    if not subset and dense and n >= 1024:
+        ks.append(_capi.KERNEL_WIDE)
     if subset:
         ks.append(_capi.KERNEL_SCAN)
     return ks
@@ -38,7 +40,7 @@ def run_engine(recs_np, v, n, kept=None, kernel=_capi.KERNEL_AUTO, record_stride
         k = eng.kept_count
         if out_stride is None:
             out_stride = 4 * k + 1
-        rec_t = torch.from_numpy(np.ascontiguousarray(recs_np)).to(DEV)
+        rec_t = torch.from_numpy(np.array(recs_np, dtype=np.uint8, copy=True)).to(DEV)
         total = out_offset + max(v, 1) * out_stride + 64
         out = torch.full((total,), SENTINEL, dtype=torch.uint8, device=DEV)
         vidx_t = None
@@ -61,7 +63,7 @@ def expect_buffer(want_rows, v, k, out_stride, out_offset, total):
 @pytest.mark.parametrize("name", case_names())
 def test_golden_cases(name):
     v, n, recs, kept, gt = load_case(name)
-    for kern in kernels_for(kept is not None, True):
+    for kern in kernels_for(kept is not None, True, n):
         got, k = run_engine(recs.reshape(-1), v, n, kept=kept, kernel=kern)
         assert bytes(got[: gt.size]) == bytes(gt), f"kernel {kern}"
         assert (got[gt.size :] == SENTINEL).all(), f"kernel {kern} wrote past the end"
@@ -76,21 +78,21 @@ def test_golden_sha_with_device_synth(name):
         recs = eng.synth_records(v, first_variant=spec["first_variant"], seed=spec["seed"], dirty_pad=spec["dirty_pad"])
         eng.wait()
         assert hashlib.sha256(recs.cpu().numpy().tobytes()).hexdigest() == spec["records_sha256"]
-        for kern in kernels_for(kept is not None, True):
+        for kern in kernels_for(kept is not None, True, n):
             out = eng.decode_emit(recs, v, kernel=kern)
             eng.wait()
             assert out.numel() == spec["gt_bytes"]
             assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == spec["gt_sha256"], f"kernel {kern}"
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 7, 15, 16, 17, 63, 64, 65, 66, 67, 255, 256, 257, 511, 513, 1023, 2504, 4099, 16385])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 66, 67, 255, 256, 257, 511, 513, 1023, 1024, 1025, 2504, 4093, 4095, 4096, 4097, 4099, 16385, 70001])
 def test_all_samples_vs_oracle(n):
     rng = np.random.default_rng(n + 1)
     v = 11
     r = oracle.variant_record_size(n)
     recs = rng.integers(0, 256, size=max(v * r, 1), dtype=np.uint8)  # dirty pad bits included
     want = oracle.decode_emit(recs, v, n).reshape(v, -1)
-    for kern in kernels_for(False, True):
+    for kern in kernels_for(False, True, n):
         got, k = run_engine(recs, v, n, kernel=kern)
         assert k == n
         exp = expect_buffer(want, v, n, 4 * n + 1, 0, got.size)
@@ -100,11 +102,11 @@ def test_all_samples_vs_oracle(n):
 @pytest.mark.parametrize("out_offset", range(0, 17))
 def test_unaligned_output_pointer(out_offset):
     rng = np.random.default_rng(100 + out_offset)
-    n, v = 131, 6
+    n, v = (131, 6) if out_offset % 2 else (1031, 5)
     r = oracle.variant_record_size(n)
     recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
     want = oracle.decode_emit(recs, v, n).reshape(v, -1)
-    for kern in kernels_for(False, True):
+    for kern in kernels_for(False, True, n):
         got, _ = run_engine(recs, v, n, kernel=kern, out_offset=out_offset)
         exp = expect_buffer(want, v, n, 4 * n + 1, out_offset, got.size)
         assert (got == exp).all(), f"kernel {kern}"
