@@ -32,13 +32,14 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr uint32_t kSpanChunks = 1024;  // chunks per work item: 16 stores x 64 lanes
 constexpr uint32_t kSlabBytes = 1088;   // 66 lanes x 16 B staged at most, rounded to 64
+constexpr uint32_t kSlabExtra = 16;     // stream kernel: first byte of the next row rides behind the slab
 
 struct WideParams {
     uint64_t row_bytes;      // S = 4N + 1
     uint64_t total_bytes;    // T = V * S
     uint64_t n_items;        // V * spans_per_row
     uint32_t spans_per_row;
-    uint32_t head;           // out address & 15
+    uint32_t head;           // out address & 127: the chunk grid is anchored at a 128-B line boundary
 };
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -64,6 +65,7 @@ __device__ __forceinline__ void store_chunk(uint8_t *dst, const u32x4 &v)
 struct Item {
     uint64_t g0;          // first chunk (index into the aligned chunk space of the stream)
     uint32_t cnt;         // chunks in this item (0 = nothing to do)
+    uint32_t lead;        // g0 - span base: store step u covers chunks base + 64u .. +63 (1-KiB aligned)
     int64_t c_first;      // row-relative byte offset of chunk g0's first byte (>= -15)
     const uint8_t *rec;   // record of row j
     const uint8_t *base;  // 16-B-aligned address the staged bytes start at
@@ -79,12 +81,17 @@ __device__ __forceinline__ Item make_item(const EmitArgs &a, const WideParams &p
     const uint64_t j = p.spans_per_row == 1u ? t : t / p.spans_per_row;
     const uint32_t k = p.spans_per_row == 1u ? 0u : (uint32_t)(t - j * p.spans_per_row);
     const uint64_t row_start = j * S;
-    // row j owns the chunks whose first byte lies in [j*S, (j+1)*S); row 0 also the head chunk
-    const uint64_t g_first = j == 0 ? 0ull : (row_start + p.head + 15ull) >> 4;
+    // row j owns the chunks whose first byte lies in [j*S, (j+1)*S); row 0 also the chunk that
+    // holds stream byte 0.  Spans are cut on 64-chunk (1 KiB) boundaries of the chunk grid so every
+    // store instruction of a wave covers eight WHOLE 128-B lines (except at the two row ends).
+    const uint64_t g_first = j == 0 ? (uint64_t)(p.head >> 4) : (row_start + p.head + 15ull) >> 4;
     const uint64_t g_end = (row_start + S + p.head + 15ull) >> 4;
+    const uint64_t span_base = (g_first & ~63ull) + (uint64_t)k * kSpanChunks;
+    const uint64_t span_end = min(g_end, span_base + kSpanChunks);
     it.row = j;
-    it.g0 = g_first + (uint64_t)k * kSpanChunks;
-    it.cnt = it.g0 < g_end ? (uint32_t)min((uint64_t)kSpanChunks, g_end - it.g0) : 0u;
+    it.g0 = max(g_first, span_base);
+    it.cnt = it.g0 < span_end ? (uint32_t)(span_end - it.g0) : 0u;
+    it.lead = (uint32_t)(it.g0 - span_base);
     it.c_first = (int64_t)(it.g0 * 16ull) - (int64_t)p.head - (int64_t)row_start;
     it.rec = row_record<HAS_VIDX>(a, j);
     const uint32_t last = a.record_size - 1u;
@@ -98,6 +105,102 @@ __device__ __forceinline__ Item make_item(const EmitArgs &a, const WideParams &p
     return it;
 }
 
+// One item's 16 store steps: lanes read their 10-bit window from the staged record bytes in
+// `slab`, expand to text and store aligned 16-byte chunks.  NEXT_IN_SLAB: the first byte of row
+// j+1 (needed by the chunk that holds row j's '\n') was parked at slab[kSlabBytes] by the loader
+// wave, so this wave never issues a global load (gfx9 has one in-order vmcnt for loads and stores:
+// a wave that waits for a load also drains all its older stores).
+template <bool HAS_VIDX, bool NT, bool NEXT_IN_SLAB>
+__device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p, const Item &it,
+                                          const uint8_t *slab, uint32_t lane)
+{
+    const uint64_t S = p.row_bytes;
+    const uint64_t gt_bytes = S - 1ull;
+    const uint32_t last = a.record_size - 1u;
+    uint8_t *const chunk0 = a.out - p.head;
+    // ---- 16 store steps over the staged bytes
+    const int32_t bf = (int32_t)(it.c_first >> 4);                 // record byte of chunk 0's window (>= -1)
+    const int32_t delta = (int32_t)(it.rec - it.base);            // slab offset of record byte 0
+    const uint32_t phase = (uint32_t)it.c_first & 15u;             // same for every chunk of the row
+    // chunks 0 .. n_interior-1 lie wholly inside the row's GT text
+    const int64_t room = (int64_t)gt_bytes - 16 - it.c_first;      // c_first + 16*i + 16 <= gt_bytes
+    const uint32_t n_interior = room < 0 ? 0u : (uint32_t)min((int64_t)it.cnt, room / 16 + 1);
+    const bool head_chunk = it.c_first < 0;                        // only (row 0, span 0) with an unaligned out
+#pragma unroll 4
+    for (uint32_t u = 0; u < kSpanChunks / 64u; u++) {
+        if (u * 64u >= it.lead + it.cnt) break;
+        const uint32_t idx = u * 64u + lane;      // position inside the 1-KiB-aligned span
+        const uint32_t i = idx - it.lead;         // chunk of this item (wraps to huge when idx < lead)
+        if (i >= it.cnt) continue;
+        uint8_t *dst = chunk0 + (it.g0 + i) * 16ull;
+        const int32_t b0 = bf + (int32_t)i;
+        uint32_t window;
+        {
+            // bytes b0, b0+1 of the record (clamped to the staged range for don't-care positions)
+            const int32_t bb = max(0, min(b0, (int32_t)last - 1));
+            uint16_t h;
+            __builtin_memcpy(&h, slab + bb + delta, 2);
+            const int32_t d = b0 - bb;
+            window = d < 0 ? ((uint32_t)h << 8) & 0xFFFFu : (uint32_t)h >> (8u * (uint32_t)min(d, 2));
+        }
+        if (i < n_interior && !(head_chunk && i == 0u)) {
+            store_chunk<NT>(dst, gt_text16_from_window(window, (int64_t)phase));
+            continue;
+        }
+        // ---- row tail: the chunk holds '\n' at byte nl (and the head of row j+1 behind it)
+        const int64_t c = it.c_first + 16ll * (int64_t)i;
+        const int64_t o = (int64_t)((it.g0 + i) * 16ull) - (int64_t)p.head;
+        const uint32_t nl = (uint32_t)((int64_t)gt_bytes - c);  // 0..15 when c >= 0
+        if (c >= 0 && (it.row + 1ull < a.n_variants || nl == 15u)) {
+            u32x4 x = gt_text16_from_window(window, c);
+            u32x4 y = {0u, 0u, 0u, 0u};
+            if (nl < 15u) {
+                const int64_t qy = -(int64_t)nl - 1;  // row j+1 starts nl+1 bytes into the chunk
+                // window of row j+1's first samples: record byte -1 (none) and byte 0
+                const uint32_t nb0 = NEXT_IN_SLAB ? (uint32_t)slab[kSlabBytes] : (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
+                y = gt_text16_from_window(nb0 << 8, qy);
+            }
+            uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+            uint32_t ys[4] = {y.x, y.y, y.z, y.w};
+            uint32_t os[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int32_t nb = (int32_t)nl - 4 * m;  // bytes of dword m taken from x
+                const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+                uint32_t v = (xs[m] & mask) | (ys[m] & ~mask);
+                if (nb >= 0 && nb < 4) v = (v & ~(0xFFu << (8 * nb))) | (0x0Au << (8 * nb));
+                os[m] = v;
+            }
+            u32x4 v = {os[0], os[1], os[2], os[3]};
+            store_chunk<NT>(dst, v);
+        } else {
+            // first/last chunk of the whole stream: byte-wise with a validity mask
+            uint64_t rr = it.row;
+            int64_t cc = c;
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const int64_t ob = o + b;
+                if (ob >= 0 && (uint64_t)ob < p.total_bytes) {
+                    if (cc >= (int64_t)S) {
+                        cc -= (int64_t)S;
+                        rr++;
+                    }
+                    uint32_t ch;
+                    if ((uint64_t)cc == gt_bytes) {
+                        ch = '\n';
+                    } else {
+                        const uint32_t s = (uint32_t)((uint64_t)cc >> 2);
+                        const uint32_t code = ((uint32_t)row_record<HAS_VIDX>(a, rr)[s >> 2] >> ((s & 3u) * 2u)) & 3u;
+                        ch = gt_text_byte(code, (uint32_t)cc & 3u);
+                    }
+                    dst[b] = (uint8_t)ch;
+                }
+                cc++;
+            }
+        }
+    }
+}
+
 template <bool HAS_VIDX, bool NT>
 __global__ __launch_bounds__(kThreads) void gt_wide_kernel(EmitArgs a, WideParams p)
 {
@@ -105,10 +208,6 @@ __global__ __launch_bounds__(kThreads) void gt_wide_kernel(EmitArgs a, WideParam
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR item math
     uint8_t *const slab = slabs[wave];
-    const uint64_t S = p.row_bytes;
-    const uint64_t gt_bytes = S - 1ull;
-    const uint32_t last = a.record_size - 1u;
-    uint8_t *const chunk0 = a.out - p.head;
     const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
 
     uint64_t t = (uint64_t)blockIdx.x * kWaves + wave;
@@ -137,89 +236,117 @@ __global__ __launch_bounds__(kThreads) void gt_wide_kernel(EmitArgs a, WideParam
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- 16 store steps over the staged bytes
-        const int32_t bf = (int32_t)(cur.c_first >> 4);                 // record byte of chunk 0's window (>= -1)
-        const int32_t delta = (int32_t)(cur.rec - cur.base);            // slab offset of record byte 0
-        const uint32_t phase = (uint32_t)cur.c_first & 15u;             // same for every chunk of the row
-        // chunks 0 .. n_interior-1 lie wholly inside the row's GT text
-        const int64_t room = (int64_t)gt_bytes - 16 - cur.c_first;      // c_first + 16*i + 16 <= gt_bytes
-        const uint32_t n_interior = room < 0 ? 0u : (uint32_t)min((int64_t)cur.cnt, room / 16 + 1);
-        const bool head_chunk = cur.c_first < 0;                        // only (row 0, span 0) with an unaligned out
-#pragma unroll 4
-        for (uint32_t u = 0; u < kSpanChunks / 64u; u++) {
-            const uint32_t i = u * 64u + lane;
-            if (u * 64u >= cur.cnt) break;
-            if (i >= cur.cnt) continue;
-            uint8_t *dst = chunk0 + (cur.g0 + i) * 16ull;
-            const int32_t b0 = bf + (int32_t)i;
-            uint32_t window;
-            {
-                // bytes b0, b0+1 of the record (clamped to the staged range for don't-care positions)
-                const int32_t bb = max(0, min(b0, (int32_t)last - 1));
-                uint16_t h;
-                __builtin_memcpy(&h, slab + bb + delta, 2);
-                const int32_t d = b0 - bb;
-                window = d < 0 ? ((uint32_t)h << 8) & 0xFFFFu : (uint32_t)h >> (8u * (uint32_t)min(d, 2));
-            }
-            if (i < n_interior && !(head_chunk && i == 0u)) {
-                store_chunk<NT>(dst, gt_text16_from_window(window, (int64_t)phase));
-                continue;
-            }
-            // ---- row tail: the chunk holds '\n' at byte nl (and the head of row j+1 behind it)
-            const int64_t c = cur.c_first + 16ll * (int64_t)i;
-            const int64_t o = (int64_t)((cur.g0 + i) * 16ull) - (int64_t)p.head;
-            const uint32_t nl = (uint32_t)((int64_t)gt_bytes - c);  // 0..15 when c >= 0
-            if (c >= 0 && (cur.row + 1ull < a.n_variants || nl == 15u)) {
-                u32x4 x = gt_text16_from_window(window, c);
-                u32x4 y = {0u, 0u, 0u, 0u};
-                if (nl < 15u) {
-                    const int64_t qy = -(int64_t)nl - 1;  // row j+1 starts nl+1 bytes into the chunk
-                    y = gt_text16_from_window(load_window<false>(row_record<HAS_VIDX>(a, cur.row + 1ull), -1, last), qy);
-                }
-                uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-                uint32_t ys[4] = {y.x, y.y, y.z, y.w};
-                uint32_t os[4];
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int32_t nb = (int32_t)nl - 4 * m;  // bytes of dword m taken from x
-                    const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
-                    uint32_t v = (xs[m] & mask) | (ys[m] & ~mask);
-                    if (nb >= 0 && nb < 4) v = (v & ~(0xFFu << (8 * nb))) | (0x0Au << (8 * nb));
-                    os[m] = v;
-                }
-                u32x4 v = {os[0], os[1], os[2], os[3]};
-                store_chunk<NT>(dst, v);
-            } else {
-                // first/last chunk of the whole stream: byte-wise with a validity mask
-                uint64_t rr = cur.row;
-                int64_t cc = c;
-#pragma unroll
-                for (int b = 0; b < 16; b++) {
-                    const int64_t ob = o + b;
-                    if (ob >= 0 && (uint64_t)ob < p.total_bytes) {
-                        if (cc >= (int64_t)S) {
-                            cc -= (int64_t)S;
-                            rr++;
-                        }
-                        uint32_t ch;
-                        if ((uint64_t)cc == gt_bytes) {
-                            ch = '\n';
-                        } else {
-                            const uint32_t s = (uint32_t)((uint64_t)cc >> 2);
-                            const uint32_t code = ((uint32_t)row_record<HAS_VIDX>(a, rr)[s >> 2] >> ((s & 3u) * 2u)) & 3u;
-                            ch = gt_text_byte(code, (uint32_t)cc & 3u);
-                        }
-                        dst[b] = (uint8_t)ch;
-                    }
-                    cc++;
-                }
-            }
-        }
+        emit_item<HAS_VIDX, NT, false>(a, p, cur, slab, lane);
         if (!more) break;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         cur = nxt;
         t = t_next;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// gt_stream_kernel — the same items, but with ROLES: wave 0 of a block only loads (global ->
+// registers -> LDS slabs), waves 1..NS only store (LDS -> text -> global).  gfx9 counts loads and
+// stores in one in-order vmcnt, so a wave that consumes a load must also wait for all of its
+// older stores; a storer wave here never waits on vmcnt, and its 1-KiB stores stream back to
+// back like a fill kernel's, while the loader keeps NS wide loads in flight one ring slot ahead.
+// Hand-off through LDS: per storer a ring of kRingSlots slabs, `full` / `done` sequence words
+// (LDS operations of one wave execute in order, and both waves live on one CU, so a flag written
+// after the slab's ds_writes is seen after them; compiler ordering is pinned with asm barriers).
+constexpr int kRingSlots = 3;
+
+// Flag words are touched with explicit DS instructions: a volatile C++ access through a generic
+// pointer would become flat_load + s_waitcnt vmcnt(0), i.e. exactly the store drain this kernel
+// exists to avoid.  The low 32 bits of a generic pointer into LDS are the LDS byte offset.
+__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)(uintptr_t)p; }
+
+__device__ __forceinline__ uint32_t lds_flag_read(uint32_t off)
+{
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ void lds_flag_write(uint32_t off, uint32_t value)
+{
+    // everything this wave sent to the LDS before (slab writes / slab reads) has completed first
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(off), "v"(value) : "memory");
+}
+
+template <int NS, bool HAS_VIDX, bool NT>
+__global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, WideParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][kRingSlots][kSlabBytes + kSlabExtra];
+    __shared__ uint32_t s_full[NS][kRingSlots];
+    __shared__ uint32_t s_done[NS][kRingSlots];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < NS * kRingSlots) {
+        (&s_full[0][0])[threadIdx.x] = 0u;
+        (&s_done[0][0])[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+
+    const uint64_t items_per_step = (uint64_t)gridDim.x * NS;
+    const uint64_t n_steps = (p.n_items + items_per_step - 1ull) / items_per_step;
+
+    if (wave == 0u) {
+        // ------------------------------ loader wave ------------------------------
+        for (uint64_t step = 0; step < n_steps; step++) {
+            const uint32_t slot = (uint32_t)(step % kRingSlots);
+            v4u in0[NS], in1[NS];
+            uint32_t nb[NS];
+            uint32_t n_load[NS];
+            // issue every storer's loads for this step, then park them
+#pragma unroll
+            for (int w = 0; w < NS; w++) {
+                const uint64_t t = step * items_per_step + (uint64_t)blockIdx.x * NS + w;
+                n_load[w] = 0u;
+                nb[w] = 0u;
+                in0[w] = v4u{0u, 0u, 0u, 0u};
+                in1[w] = v4u{0u, 0u, 0u, 0u};
+                if (t < p.n_items) {
+                    const Item it = make_item<HAS_VIDX>(a, p, t);
+                    n_load[w] = it.n_load;
+                    if (lane < it.n_load) in0[w] = *reinterpret_cast<const v4u *>(it.base + lane * 16u);
+                    if (lane + 64u < it.n_load) in1[w] = *reinterpret_cast<const v4u *>(it.base + (lane + 64u) * 16u);
+                    // the chunk holding this row's '\n' needs the first record byte of row j+1
+                    const bool row_tail = it.cnt != 0u && it.c_first + 16ll * (int64_t)it.cnt >= (int64_t)p.row_bytes;
+                    if (row_tail && it.row + 1ull < a.n_variants && lane == 0u)
+                        nb[w] = (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < NS; w++) {
+                const uint64_t t = step * items_per_step + (uint64_t)blockIdx.x * NS + w;
+                if (t >= p.n_items) continue;
+                // the slot's previous tenant (step - kRingSlots) must have been consumed
+                if (step >= (uint64_t)kRingSlots) {
+                    const uint32_t want = (uint32_t)(step - kRingSlots) + 1u;
+                    while (lds_flag_read(lds_offset(&s_done[w][slot])) != want) __builtin_amdgcn_s_sleep(1);
+                }
+                uint8_t *slab = slabs[w][slot];
+                *reinterpret_cast<v4u *>(slab + lane * 16u) = in0[w];
+                if (lane < 4u) *reinterpret_cast<v4u *>(slab + (lane + 64u) * 16u) = in1[w];
+                if (lane == 0u) slab[kSlabBytes] = (uint8_t)nb[w];
+                if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), (uint32_t)step + 1u);
+            }
+        }
+    } else {
+        // ------------------------------ storer waves -----------------------------
+        const uint32_t w = wave - 1u;
+        for (uint64_t step = 0; step < n_steps; step++) {
+            const uint64_t t = step * items_per_step + (uint64_t)blockIdx.x * NS + w;
+            if (t >= p.n_items) break;
+            const uint32_t slot = (uint32_t)(step % kRingSlots);
+            const Item it = make_item<HAS_VIDX>(a, p, t);
+            while (lds_flag_read(lds_offset(&s_full[w][slot])) != (uint32_t)step + 1u) __builtin_amdgcn_s_sleep(1);
+            emit_item<HAS_VIDX, NT, true>(a, p, it, slabs[w][slot], lane);
+            // every ds_read of the slab has returned (its data fed the stores above): release the slot
+            if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), (uint32_t)step + 1u);
+        }
     }
 }
 
@@ -238,16 +365,34 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
     WideParams p;
     p.row_bytes = 4ull * a.kept_count + 1ull;
     p.total_bytes = (uint64_t)a.n_variants * p.row_bytes;
-    p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 15ull);
-    // a row owns floor(S/16) or ceil(S/16) chunks (one more for row 0 with an unaligned pointer)
-    const uint64_t max_row_chunks = (p.row_bytes + 15ull) / 16ull + 1ull;
+    p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 127ull);
+    // a row owns floor(S/16) or ceil(S/16) chunks (one more for row 0 with an unaligned pointer), and
+    // its first span starts up to 63 chunks before them (1-KiB-aligned span grid)
+    const uint64_t max_row_chunks = (p.row_bytes + 15ull) / 16ull + 1ull + 63ull;
     p.spans_per_row = (uint32_t)((max_row_chunks + kSpanChunks - 1ull) / kSpanChunks);
     p.n_items = (uint64_t)a.n_variants * p.spans_per_row;
 
     const char *eb = getenv("PGENHIP_WIDE_BLOCKS_PER_CU");
-    const int blocks_per_cu = eb ? atoi(eb) : (p.spans_per_row == 1u ? 4 : 8);
+    const int blocks_per_cu = eb ? atoi(eb) : 8;
     const char *en = getenv("PGENHIP_WIDE_NT");
-    const bool nt = en ? atoi(en) != 0 : false;
+    const bool nt = en ? atoi(en) != 0 : true;
+    const char *es = getenv("PGENHIP_WIDE_STREAM");  // 0 = symmetric waves, 3 / 7 = storer waves per block
+    const int stream_ns = es ? atoi(es) : 7;  // default: 1 loader + 7 storer waves (interleaved A/B: profiles/r01_kernel_sweeps.md)
+    if (stream_ns == 3 || stream_ns == 7) {
+        const uint64_t need = (p.n_items + (uint64_t)stream_ns - 1ull) / (uint64_t)stream_ns;
+        const uint64_t cap = (uint64_t)num_cus * (uint64_t)blocks_per_cu;
+        const uint32_t g = (uint32_t)(need < cap ? need : cap);
+        void (*sk)(EmitArgs, WideParams);
+        if (stream_ns == 3) {
+            if (a.variant_idx) sk = nt ? gt_stream_kernel<3, true, true> : gt_stream_kernel<3, true, false>;
+            else sk = nt ? gt_stream_kernel<3, false, true> : gt_stream_kernel<3, false, false>;
+        } else {
+            if (a.variant_idx) sk = nt ? gt_stream_kernel<7, true, true> : gt_stream_kernel<7, true, false>;
+            else sk = nt ? gt_stream_kernel<7, false, true> : gt_stream_kernel<7, false, false>;
+        }
+        hipLaunchKernelGGL(sk, dim3(g), dim3(64 * (stream_ns + 1)), 0, stream, a, p);
+        return hipGetLastError();
+    }
     const uint64_t blocks_needed = (p.n_items + kWaves - 1ull) / kWaves;
     const uint64_t max_grid = (uint64_t)num_cus * (uint64_t)blocks_per_cu;
     const uint32_t grid = (uint32_t)(blocks_needed < max_grid ? blocks_needed : max_grid);

@@ -24,7 +24,7 @@ def run(n, v, kernel, env, rounds=5):
 if __name__ == "__main__":
     for n, v in ((2504, 1_103_547), (500_000, 6_000)):
         run(n, v, 2, {"PGENHIP_FLAT_VARIANT": 1, "PGENHIP_FLAT_BLOCKS_PER_CU": 64})
-        run(n, v, 2, {"PGENHIP_FLAT_VARIANT": 0, "PGENHIP_FLAT_BLOCKS_PER_CU": 8})
-        for bpc in (1, 2, 4, 6, 8):
-            for nt in (0, 1):
-                run(n, v, 4, {"PGENHIP_WIDE_BLOCKS_PER_CU": bpc, "PGENHIP_WIDE_NT": nt})
+        for ns in (0, 3, 7):
+            for bpc in (2, 3, 4, 6, 8):
+                for nt in (0, 1):
+                    run(n, v, 4, {"PGENHIP_WIDE_STREAM": ns, "PGENHIP_WIDE_BLOCKS_PER_CU": bpc, "PGENHIP_WIDE_NT": nt})

@@ -271,3 +271,26 @@ def test_large_shape_properties_config3_rows():
     want_code = ((host.reshape(v, -1)[:, :, None] >> shifts) & 3).reshape(v, -1)[:, :n]
     assert (code == want_code).all()
     assert rows.tobytes() == oracle.decode_emit(host, v, n).tobytes()
+
+
+@pytest.mark.parametrize("stream,nt", [(0, 0), (0, 1), (3, 0), (3, 1), (7, 0), (7, 1)])
+def test_wide_kernel_variants(monkeypatch, stream, nt):
+    """Every build of the wide kernel (symmetric waves / 1 loader + 3 or 7 storer waves, plain or
+    nontemporal stores) against the oracle, on shapes with 1 and several spans per row."""
+    monkeypatch.setenv("PGENHIP_WIDE_STREAM", str(stream))
+    monkeypatch.setenv("PGENHIP_WIDE_NT", str(nt))
+    monkeypatch.setenv("PGENHIP_WIDE_BLOCKS_PER_CU", "2")
+    rng = np.random.default_rng(500 + stream * 2 + nt)
+    for n, v, off in [(2504, 301, 0), (1024, 77, 5), (4099, 40, 0), (40001, 9, 3), (70001, 5, 0)]:
+        r = oracle.variant_record_size(n)
+        recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
+        want = oracle.decode_emit(recs, v, n).reshape(v, -1)
+        got, _ = run_engine(recs, v, n, kernel=_capi.KERNEL_WIDE, out_offset=off)
+        exp = expect_buffer(want, v, n, 4 * n + 1, off, got.size)
+        assert (got == exp).all(), f"n={n} v={v} off={off}"
+    vidx = [5, 0, 3, 3, 9]
+    n = 3000
+    recs = rng.integers(0, 256, size=10 * oracle.variant_record_size(n), dtype=np.uint8)
+    want = oracle.decode_emit(recs, len(vidx), n, variant_idx=vidx).reshape(len(vidx), -1)
+    got, _ = run_engine(recs, len(vidx), n, kernel=_capi.KERNEL_WIDE, variant_idx=vidx)
+    assert (got == expect_buffer(want, len(vidx), n, 4 * n + 1, 0, got.size)).all()
