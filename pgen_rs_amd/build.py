@@ -70,10 +70,29 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
     return HIP_LIB
 
 
+HOST_DIR = PKG_DIR / "host"
+HOST_BIN = PKG_DIR / "pgen-hip"
+HOST_SOURCES = ["cli.cpp", "pfile.cpp", "csvlite.cpp", "expr.cpp"]
+
+
+def build_host(force: bool = False, verbose: bool = False) -> Path:
+    """The C++ host (pgen-rs's Pfile/CLI surface) — plain g++, links only the C ABI."""
+    srcs = [HOST_DIR / s for s in HOST_SOURCES]
+    deps = srcs + sorted(HOST_DIR.glob("*.h")) + [REPO_ROOT / "include" / "pgen_hip.h", HIP_LIB, Path(__file__)]
+    if force or _stale(HOST_BIN, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-I", str(REPO_ROOT / "include"),
+               "-o", str(HOST_BIN), *map(str, srcs), "-L", str(PKG_DIR), "-lpgen_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd, HOST_DIR)
+    return HOST_BIN
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip(force=force, verbose=verbose)
+    build_host(force=force, verbose=verbose)
 
 
 if __name__ == "__main__":
     build_all(force="--force" in sys.argv, verbose=True)
-    print("built", HIP_LIB)
+    print("built", HIP_LIB, "and", HOST_BIN)

@@ -1,0 +1,217 @@
+// cli.cpp — `pgen-hip`: the pgen-rs command-line surface (src/cli.rs:1-62, dispatch
+// src/main.rs:92-127) on top of the MI355X engine.  Same subcommands, flags and defaults:
+//
+//   pgen-hip query  <PFILE_PREFIX> -f|--fstring <EXPR> [-i|--include <EXPR>] [-s|--samples]
+//   pgen-hip filter <PFILE_PREFIX> [--include-var <EXPR>] [--include-sam <EXPR>] [-o|--out <FILE>]
+//
+// Additions (opt-in, not in the reference): --gpus <N>, --block-mib <M>, --stats, --dry-run
+// (filter: write the VCF header only and report the body geometry; needs no GPU).
+// Exit codes: 0 ok; 2 usage error (clap's code); 101 where the reference would panic.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "expr.h"
+#include "pfile.h"
+
+using namespace pgenhost;
+
+namespace {
+
+const char *kUsage =
+    "Usage: pgen-hip <COMMAND>\n\n"
+    "Commands:\n"
+    "  query   Queries the pgen, outputting to stdout\n"
+    "  filter  Filters the pgen, outputting to a VCF\n"
+    "  help    Print this message\n\n"
+    "query  <PFILE_PREFIX> -f, --fstring <QUERY_FSTRING> [-i, --include <QUERY>] [-s, --samples]\n"
+    "filter <PFILE_PREFIX> [--include-var <VAR_QUERY>] [--include-sam <SAM_QUERY>] [-o, --out <OUT_FILE>]\n"
+    "       [--gpus <N>] [--block-mib <M>] [--stats] [--dry-run]\n";
+
+[[noreturn]] void usage_error(const std::string &msg)
+{
+    std::fprintf(stderr, "error: %s\n\n%s", msg.c_str(), kUsage);
+    std::exit(2);
+}
+
+struct Args {
+    std::vector<std::string> positional;
+    std::vector<std::pair<std::string, std::string>> options;  // name (without dashes) -> value ("" for flags)
+    bool has(const std::string &n) const
+    {
+        for (const auto &o : options)
+            if (o.first == n) return true;
+        return false;
+    }
+    std::optional<std::string> get(const std::string &n) const
+    {
+        std::optional<std::string> v;
+        for (const auto &o : options)
+            if (o.first == n) v = o.second;
+        return v;
+    }
+};
+
+// clap-style: long `--name value` / `--name=value`, short `-f value` / `-fvalue`, flags without values
+Args parse(int argc, char **argv, int first, const std::vector<std::pair<std::string, char>> &valued,
+           const std::vector<std::pair<std::string, char>> &flags)
+{
+    Args a;
+    auto long_of_short = [&](char c, bool &is_flag) -> std::string {
+        for (const auto &v : valued)
+            if (v.second == c) { is_flag = false; return v.first; }
+        for (const auto &f : flags)
+            if (f.second == c) { is_flag = true; return f.first; }
+        return std::string();
+    };
+    auto is_valued = [&](const std::string &n) {
+        for (const auto &v : valued)
+            if (v.first == n) return true;
+        return false;
+    };
+    auto is_flag = [&](const std::string &n) {
+        for (const auto &f : flags)
+            if (f.first == n) return true;
+        return false;
+    };
+    bool only_positional = false;
+    for (int i = first; i < argc; i++) {
+        std::string s = argv[i];
+        if (only_positional || s.size() < 2 || s[0] != '-') {
+            a.positional.push_back(s);
+            continue;
+        }
+        if (s == "--") {
+            only_positional = true;
+            continue;
+        }
+        if (s[1] == '-') {
+            std::string name = s.substr(2), value;
+            const size_t eq = name.find('=');
+            const bool inline_value = eq != std::string::npos;
+            if (inline_value) {
+                value = name.substr(eq + 1);
+                name = name.substr(0, eq);
+            }
+            if (is_valued(name)) {
+                if (!inline_value) {
+                    if (i + 1 >= argc) usage_error("a value is required for '--" + name + "' but none was supplied");
+                    value = argv[++i];
+                }
+                a.options.emplace_back(name, value);
+            } else if (is_flag(name)) {
+                a.options.emplace_back(name, "");
+            } else {
+                usage_error("unexpected argument '--" + name + "' found");
+            }
+        } else {
+            bool flag = false;
+            const std::string name = long_of_short(s[1], flag);
+            if (name.empty()) usage_error(std::string("unexpected argument '-") + s[1] + "' found");
+            if (flag) {
+                a.options.emplace_back(name, "");
+            } else {
+                std::string value = s.substr(2);
+                if (!value.empty() && value[0] == '=') value = value.substr(1);
+                if (s.size() == 2) {
+                    if (i + 1 >= argc) usage_error("a value is required for '-" + std::string(1, s[1]) + "' but none was supplied");
+                    value = argv[++i];
+                }
+                a.options.emplace_back(name, value);
+            }
+        }
+    }
+    return a;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) usage_error("a subcommand is required");
+    const std::string cmd = argv[1];
+    try {
+        if (cmd == "help" || cmd == "--help" || cmd == "-h") {
+            std::fputs(kUsage, stdout);
+            return 0;
+        }
+        if (cmd == "--version" || cmd == "-V") {
+            std::puts("pgen-hip 0.1.0 (MI355X engine for pgen-rs's filter/query surface)");
+            return 0;
+        }
+        if (cmd == "query") {  // src/main.rs:95-113
+            Args a = parse(argc, argv, 2, {{"fstring", 'f'}, {"include", 'i'}}, {{"samples", 's'}});
+            if (a.positional.size() != 1) usage_error("the following required arguments were not provided: <PFILE_PREFIX>");
+            if (!a.has("fstring")) usage_error("the following required arguments were not provided: --fstring <QUERY_FSTRING>");
+            const Pfile pfile = Pfile::from_prefix(a.positional[0]);
+            const std::string path = a.has("samples") ? pfile.psam_path() : pfile.pvar_path();
+            const std::string data = read_file(path);
+            TsvReader reader(data, Pfile::find_metadata_file_header_start(data));
+            std::string out;
+            Pfile::query_metadata(reader, a.get("include"), *a.get("fstring"), out);
+            std::fwrite(out.data(), 1, out.size(), stdout);
+            return 0;
+        }
+        if (cmd == "filter") {  // src/main.rs:114-124
+            Args a = parse(argc, argv, 2, {{"include-var", 0}, {"include-sam", 0}, {"out", 'o'}, {"gpus", 0}, {"block-mib", 0}},
+                           {{"stats", 0}, {"dry-run", 0}});
+            if (a.positional.size() != 1) usage_error("the following required arguments were not provided: <PFILE_PREFIX>");
+            const Pfile pfile = Pfile::from_prefix(a.positional[0]);
+            const std::string out_file = a.get("out").value_or(pfile.pfile_prefix + ".pgen-rs.vcf");  // :121-122
+            if (a.has("dry-run")) {
+                // header + geometry only: the plumbing of BASELINE config 1 without touching a GPU
+                const std::string psam = read_file(pfile.psam_path());
+                TsvReader psam_reader(psam, Pfile::find_metadata_file_header_start(psam));
+                const StringRecord sam_header = psam_reader.headers();
+                const std::string pvar = read_file(pfile.pvar_path());
+                TsvReader pvar_reader(pvar, Pfile::find_metadata_file_header_start(pvar));
+                const auto vars = Pfile::filter_metadata(pvar_reader, a.get("include-var"));
+                const auto sams = Pfile::filter_metadata(psam_reader, a.get("include-sam"));
+                const std::string header = pfile.vcf_header(sams, sam_header);
+                FILE *f = std::fopen(out_file.c_str(), "wb");
+                if (!f) throw PfileError("create " + out_file + ": " + std::strerror(errno));
+                std::fwrite(header.data(), 1, header.size(), f);
+                std::fclose(f);
+                unsigned long long prefix = 0;
+                for (const auto &v : vars) {
+                    prefix += 2;
+                    for (const auto &c : v.second) prefix += c.size() + 1;
+                }
+                const unsigned long long body = prefix + (unsigned long long)vars.size() * (4ull * sams.size() + 1ull);
+                std::printf("{\"variants_kept\": %zu, \"samples_kept\": %zu, \"header_bytes\": %zu, \"prefix_bytes\": %llu, \"body_bytes\": %llu, \"file_bytes\": %llu}\n",
+                            vars.size(), sams.size(), header.size(), prefix, body, (unsigned long long)header.size() + body);
+                return 0;
+            }
+            OutputOptions opt;
+            if (auto g = a.get("gpus")) opt.n_gpus = std::max(1, std::atoi(g->c_str()));
+            if (auto m = a.get("block-mib")) opt.block_text_bytes = (uint64_t)std::max(1, std::atoi(m->c_str())) << 20;
+            const OutputStats st = pfile.output_vcf(a.get("include-sam"), a.get("include-var"), out_file, opt);  // :123
+            if (a.has("stats")) {
+                std::fprintf(stderr,
+                             "{\"variants_kept\": %llu, \"samples_kept\": %llu, \"header_bytes\": %llu, \"body_bytes\": %llu, "
+                             "\"seconds_filter\": %.6f, \"seconds_body\": %.6f, \"seconds_kernel\": %.6f}\n",
+                             (unsigned long long)st.variants, (unsigned long long)st.samples_kept, (unsigned long long)st.header_bytes,
+                             (unsigned long long)st.body_bytes, st.seconds_filter, st.seconds_body, st.seconds_kernel);
+            }
+            return 0;
+        }
+        usage_error("unrecognized subcommand '" + cmd + "'");
+    } catch (const PfileError &e) {
+        std::fprintf(stderr, "pgen-hip: %s\n", e.what());
+        return 101;
+    } catch (const CsvError &e) {
+        std::fprintf(stderr, "pgen-hip: %s\n", e.what());
+        return 101;
+    } catch (const ExprError &e) {
+        std::fprintf(stderr, "pgen-hip: %s\n", e.what());
+        return 101;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "pgen-hip: %s\n", e.what());
+        return 101;
+    }
+    return 0;
+}

@@ -1,0 +1,398 @@
+// pfile.cpp — see pfile.h.  Line references are to /root/reference/src/pfile.rs.
+#include "pfile.h"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <thread>
+
+#include "../../include/pgen_hip.h"
+#include "expr.h"
+
+namespace pgenhost {
+
+namespace {
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+[[noreturn]] void fail_status(int rc, const std::string &what)
+{
+    std::string msg = what + ": " + pgenhip_strerror(rc);
+    const char *detail = pgenhip_last_error_detail();
+    if (detail && *detail) msg += std::string(" (") + detail + ")";
+    throw PfileError(msg);
+}
+
+void check(int rc, const char *what)
+{
+    if (rc != PGENHIP_OK) fail_status(rc, what);
+}
+
+// std::io::BufRead::read_line: up to and including '\n'; empty at EOF
+std::string read_line(const std::string &data, size_t &pos)
+{
+    if (pos >= data.size()) return std::string();
+    size_t nl = data.find('\n', pos);
+    size_t end = nl == std::string::npos ? data.size() : nl + 1;
+    std::string line = data.substr(pos, end - pos);
+    pos = end;
+    return line;
+}
+
+// str::trim() of Rust for the ASCII whitespace that can occur here
+std::string trim(const std::string &s)
+{
+    size_t b = 0, e = s.size();
+    auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; };
+    while (b < e && ws(s[b])) b++;
+    while (e > b && ws(s[e - 1])) e--;
+    return s.substr(b, e - b);
+}
+
+void pread_exact(int fd, void *dst, size_t bytes, uint64_t offset, const std::string &path)
+{
+    uint8_t *p = static_cast<uint8_t *>(dst);
+    while (bytes) {
+        ssize_t r = pread(fd, p, bytes, (off_t)offset);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            throw PfileError("read " + path + ": " + std::strerror(errno));
+        }
+        if (r == 0) throw PfileError("read " + path + ": failed to fill whole buffer (record past end of file)");  // :170 read_exact
+        p += r;
+        bytes -= (size_t)r;
+        offset += (uint64_t)r;
+    }
+}
+
+void pwrite_exact(int fd, const void *src, size_t bytes, uint64_t offset, const std::string &path)
+{
+    const uint8_t *p = static_cast<const uint8_t *>(src);
+    while (bytes) {
+        ssize_t w = pwrite(fd, p, bytes, (off_t)offset);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            throw PfileError("write " + path + ": " + std::strerror(errno));
+        }
+        p += w;
+        bytes -= (size_t)w;
+        offset += (uint64_t)w;
+    }
+}
+
+}  // namespace
+
+std::string read_file(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw PfileError("open " + path + ": " + std::strerror(errno));  // File::open(..).unwrap()
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+// :38-76
+Pfile Pfile::from_prefix(const std::string &pfile_prefix)
+{
+    Pfile pf;
+    pf.pfile_prefix = pfile_prefix;
+    const std::string path = pf.pgen_path();
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw PfileError("open " + path + ": " + std::strerror(errno));  // :41
+    uint8_t hdr[12];
+    ssize_t got = pread(fd, hdr, sizeof hdr, 0);
+    close(fd);
+    if (got != (ssize_t)sizeof hdr) throw PfileError("read " + path + ": failed to fill whole buffer");  // :45 read_exact
+    int rc = pgenhip_parse_header(hdr, &pf.num_variants, &pf.num_samples);
+    if (rc == PGENHIP_ERR_BAD_MAGIC) throw PfileError(path + ": assertion failed: magic number is not [0x6C, 0x1B]");          // :47
+    if (rc == PGENHIP_ERR_BAD_MODE) throw PfileError(path + ": assertion failed: storage_mode == 0x02 (only the fixed-width mode is supported)");  // :53
+    if (rc == PGENHIP_ERR_BAD_FLAGS) throw PfileError(path + ": assertion failed: header byte 11 is not 0x40");                // :69
+    check(rc, "pgenhip_parse_header");
+    return pf;
+}
+
+// :196-200
+uint32_t Pfile::variant_record_size() const { return pgenhip_variant_record_size(num_samples); }
+
+// :202-220
+std::pair<std::string, std::string> Pfile::read_pvar_header() const
+{
+    const std::string data = read_file(pvar_path());
+    std::vector<std::string> header_lines;
+    size_t pos = 0;
+    for (;;) {
+        std::string buf = read_line(data, pos);
+        if (!buf.empty() && buf[0] == '#')
+            header_lines.push_back(buf);
+        else
+            break;
+    }
+    if (header_lines.empty()) throw PfileError(pvar_path() + ": no '#' header line (called `Option::unwrap()` on a `None` value)");  // :217
+    std::string header = header_lines.back();
+    header_lines.pop_back();
+    std::string joined;
+    for (const auto &l : header_lines) joined += l;
+    return {joined, header};
+}
+
+// :248-268
+uint64_t Pfile::find_metadata_file_header_start(const std::string &data)
+{
+    size_t pos = 0;
+    std::string prev_buf, buf;
+    for (;;) {
+        prev_buf = buf;
+        buf = read_line(data, pos);
+        if (buf.empty() || buf[0] != '#') {
+            const uint64_t current_pos = pos;
+            const uint64_t offset = (uint64_t)(buf.size() + prev_buf.size()) - 1ull;  // wraps like Rust would panic only in debug
+            return current_pos - offset;
+        }
+    }
+}
+
+// :312-335
+Pfile::IdxRecords Pfile::filter_metadata(TsvReader &reader, const std::optional<std::string> &query)
+{
+    IdxRecords kept;
+    std::optional<Expr> expr;
+    if (query) {
+        expr.emplace(*query);
+        expr->bind(reader.headers());
+    }
+    StringRecord rcd;
+    size_t idx = 0;
+    while (reader.next(rcd)) {
+        const bool keep = expr ? expr->eval_boolean(rcd) : true;  // :321-329
+        if (keep) kept.emplace_back(idx, rcd);                    // :330-332
+        idx++;
+    }
+    return kept;
+}
+
+// :78-102
+void Pfile::query_metadata(TsvReader &reader, const std::optional<std::string> &query, const std::string &f_string, std::string &out)
+{
+    std::optional<Expr> filter;
+    if (query) {
+        filter.emplace(*query);
+        filter->bind(reader.headers());
+    }
+    Expr fmt(f_string);
+    fmt.bind(reader.headers());
+    StringRecord rcd;
+    while (reader.next(rcd)) {
+        const bool keep = filter ? filter->eval_boolean(rcd) : true;  // :93-95
+        if (keep) {
+            out += fmt.eval_string(rcd);  // :97
+            out += '\n';                  // println!
+        }
+    }
+}
+
+// :110-146 minus the file handling
+std::string Pfile::vcf_header(const IdxRecords &sam_idx_rcs, const StringRecord &sam_header) const
+{
+    auto [pvar_header, pvar_column_names] = read_pvar_header();  // :110
+    size_t iid = sam_header.size();
+    for (size_t c = 0; c < sam_header.size(); c++) {  // :114-124 find_map: first match
+        if (sam_header[c] == "IID") {
+            iid = c;
+            break;
+        }
+    }
+    if (iid == sam_header.size()) throw PfileError("IID not among the headers of " + psam_path());  // :125-126
+    std::string sam_ids;  // :130-134
+    for (size_t k = 0; k < sam_idx_rcs.size(); k++) {
+        if (k) sam_ids += '\t';
+        sam_ids += sam_idx_rcs[k].second.at(iid);
+    }
+    std::string h = "##fileformat=VCFv4.2\n##source=pgen-rs\n";  // :139-140
+    h += pvar_header;                                              // :141
+    h += trim(pvar_column_names);                                  // :144-145
+    h += "\tFORMAT\t" + sam_ids + "\n";                            // :146
+    return h;
+}
+
+namespace {
+
+struct DeviceBuffers {
+    pgenhip_ctx *ctx = nullptr;
+    void *h_rec = nullptr, *h_blob = nullptr, *h_off = nullptr, *h_text = nullptr;
+    void *d_rec = nullptr, *d_blob = nullptr, *d_off = nullptr, *d_text = nullptr;
+    ~DeviceBuffers()
+    {
+        if (!ctx) return;
+        pgenhip_host_free_pinned(ctx, h_rec);
+        pgenhip_host_free_pinned(ctx, h_blob);
+        pgenhip_host_free_pinned(ctx, h_off);
+        pgenhip_host_free_pinned(ctx, h_text);
+        pgenhip_device_free(ctx, d_rec);
+        pgenhip_device_free(ctx, d_blob);
+        pgenhip_device_free(ctx, d_off);
+        pgenhip_device_free(ctx, d_text);
+        pgenhip_destroy(ctx);
+    }
+};
+
+}  // namespace
+
+// :104-194
+OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const std::optional<std::string> &var_query,
+                              const std::string &filename, const OutputOptions &opt) const
+{
+    OutputStats st;
+    const double t0 = now_s();
+    const std::string psam = read_file(psam_path());  // :111
+    TsvReader psam_reader(psam, find_metadata_file_header_start(psam));
+    const StringRecord sam_header = psam_reader.headers();  // :112
+    const std::string pvar = read_file(pvar_path());
+    TsvReader pvar_reader(pvar, find_metadata_file_header_start(pvar));
+    const IdxRecords var_idx_rcds = filter_metadata(pvar_reader, var_query);  // :127
+    const IdxRecords sam_idx_rcs = filter_metadata(psam_reader, sam_query);   // :128
+    const std::string header = vcf_header(sam_idx_rcs, sam_header);
+    st.seconds_filter = now_s() - t0;
+
+    int fd = open(filename.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);  // :136 File::create
+    if (fd < 0) throw PfileError("create " + filename + ": " + std::strerror(errno));
+    struct FdGuard {
+        int fd;
+        ~FdGuard() { close(fd); }
+    } guard{fd};
+    pwrite_exact(fd, header.data(), header.size(), 0, filename);  // :139-146
+
+    // ---- geometry of the body (:156-192): line j = prefix_j + K x "\tA/B" + "\n"
+    const uint32_t N = num_samples;
+    const uint32_t R = variant_record_size();
+    const size_t V = var_idx_rcds.size();
+    std::vector<uint32_t> kept;
+    kept.reserve(sam_idx_rcs.size());
+    for (const auto &ir : sam_idx_rcs) {
+        if (ir.first >= N) throw PfileError("index out of bounds: sample row " + std::to_string(ir.first) + " but the .pgen holds " + std::to_string(N) + " samples");  // :173
+        kept.push_back((uint32_t)ir.first);
+    }
+    const bool all_samples = kept.size() == (size_t)N;  // every row kept: the K = N fast path
+    const uint64_t K = kept.size();
+    std::vector<uint64_t> file_off(V + 1, 0);  // body-relative offset of each line
+    uint64_t max_prefix = 0;
+    for (size_t j = 0; j < V; j++) {
+        uint64_t plen = 2;  // "GT" (:161)
+        for (const auto &col : var_idx_rcds[j].second) plen += col.size() + 1;  // col + '\t' (:157-160)
+        max_prefix = std::max(max_prefix, plen);
+        file_off[j + 1] = file_off[j] + plen + 4ull * K + 1ull;
+        if (var_idx_rcds[j].first >= num_variants)
+            throw PfileError("variant row " + std::to_string(var_idx_rcds[j].first) + " is past the " + std::to_string(num_variants) + " records of " + pgen_path());
+    }
+    st.variants = V;
+    st.samples_kept = K;
+    st.header_bytes = header.size();
+    st.body_bytes = file_off[V];
+    if (V == 0) return st;
+
+    int n_dev = 0;
+    check(pgenhip_device_count(&n_dev), "pgenhip_device_count");
+    if (n_dev <= 0) throw PfileError("no HIP device: the GT decode/emit path has no CPU fallback");
+    const int G = std::max(1, std::min(opt.n_gpus, n_dev));
+    const double t_body = now_s();
+    std::mutex err_mu;
+    std::string err;
+    std::vector<double> kernel_s((size_t)G, 0.0);
+    const std::string pgen = pgen_path();
+
+    auto worker = [&](int g) {
+        try {
+            // contiguous range of the kept-variant list per device, sizes differ by <= 1
+            const size_t base = V / (size_t)G, extra = V % (size_t)G;
+            const size_t begin = (size_t)g * base + std::min((size_t)g, extra);
+            const size_t end = begin + base + ((size_t)g < extra ? 1 : 0);
+            if (begin == end) return;
+            int pfd = open(pgen.c_str(), O_RDONLY);  // :149 (unbuffered on purpose, :150-152)
+            if (pfd < 0) throw PfileError("open " + pgen + ": " + std::strerror(errno));
+            FdGuard pg{pfd};
+            DeviceBuffers B;
+            check(pgenhip_create(&B.ctx, g, N, all_samples ? nullptr : kept.data(), (uint32_t)K, 0), "pgenhip_create");
+            // variants per block: bounded by the text budget
+            const uint64_t max_line = max_prefix + 4ull * K + 1ull;
+            const uint64_t bv = std::max<uint64_t>(1, std::min<uint64_t>(opt.block_text_bytes / max_line, end - begin));
+            const size_t rec_bytes = (size_t)(bv * R), blob_bytes = (size_t)(bv * max_prefix), text_bytes = (size_t)(bv * max_line);
+            const size_t off_bytes = (size_t)(2 * (bv + 1) * sizeof(uint64_t));
+            check(pgenhip_host_malloc_pinned(B.ctx, &B.h_rec, rec_bytes), "pinned records");
+            check(pgenhip_host_malloc_pinned(B.ctx, &B.h_blob, blob_bytes), "pinned prefixes");
+            check(pgenhip_host_malloc_pinned(B.ctx, &B.h_off, off_bytes), "pinned offsets");
+            check(pgenhip_host_malloc_pinned(B.ctx, &B.h_text, text_bytes), "pinned text");
+            check(pgenhip_device_malloc(B.ctx, &B.d_rec, rec_bytes), "device records");
+            check(pgenhip_device_malloc(B.ctx, &B.d_blob, blob_bytes), "device prefixes");
+            check(pgenhip_device_malloc(B.ctx, &B.d_off, off_bytes), "device offsets");
+            check(pgenhip_device_malloc(B.ctx, &B.d_text, text_bytes), "device text");
+            uint8_t *h_rec = static_cast<uint8_t *>(B.h_rec);
+            char *h_blob = static_cast<char *>(B.h_blob);
+            uint64_t *h_poff = static_cast<uint64_t *>(B.h_off);
+            uint64_t *h_loff = h_poff + (bv + 1);
+
+            for (size_t b0 = begin; b0 < end; b0 += (size_t)bv) {
+                const size_t nv = std::min<size_t>((size_t)bv, end - b0);
+                // :165-170 once per run of consecutive variant indices instead of once per variant
+                for (size_t j = 0; j < nv;) {
+                    size_t run = 1;
+                    while (j + run < nv && var_idx_rcds[b0 + j + run].first == var_idx_rcds[b0 + j].first + run) run++;
+                    pread_exact(pfd, h_rec + j * R, run * (size_t)R, pgenhip_record_offset(var_idx_rcds[b0 + j].first, R), pgen);
+                    j += run;
+                }
+                // :157-161 joined once per variant: col '\t' col '\t' ... "GT"
+                uint64_t bp = 0;
+                for (size_t j = 0; j < nv; j++) {
+                    h_poff[j] = bp;
+                    h_loff[j] = file_off[b0 + j] - file_off[b0];
+                    for (const auto &col : var_idx_rcds[b0 + j].second) {
+                        std::memcpy(h_blob + bp, col.data(), col.size());
+                        bp += col.size();
+                        h_blob[bp++] = '\t';
+                    }
+                    h_blob[bp++] = 'G';
+                    h_blob[bp++] = 'T';
+                }
+                h_poff[nv] = bp;
+                const uint64_t block_bytes = file_off[b0 + nv] - file_off[b0];
+                h_loff[nv] = block_bytes;
+                check(pgenhip_memcpy_h2d(B.ctx, B.d_rec, h_rec, nv * (size_t)R), "H2D records");
+                check(pgenhip_memcpy_h2d(B.ctx, B.d_blob, h_blob, (size_t)bp), "H2D prefixes");
+                check(pgenhip_memcpy_h2d(B.ctx, B.d_off, h_poff, off_bytes), "H2D offsets");
+                check(pgenhip_timer_start(B.ctx), "timer");
+                check(pgenhip_emit_lines(B.ctx, B.d_rec, R, nullptr, (uint32_t)nv, B.d_blob, static_cast<uint64_t *>(B.d_off),
+                                         static_cast<uint64_t *>(B.d_off) + (bv + 1), max_prefix, B.d_text, 0),
+                      "pgenhip_emit_lines");
+                float ms = 0;
+                check(pgenhip_timer_stop(B.ctx, &ms), "timer");
+                kernel_s[(size_t)g] += ms * 1e-3;
+                check(pgenhip_memcpy_d2h(B.ctx, B.h_text, B.d_text, (size_t)block_bytes), "D2H text");
+                check(pgenhip_wait(B.ctx), "pgenhip_wait");
+                // every line has a known length, so ranges land at precomputed offsets in any order
+                pwrite_exact(fd, B.h_text, (size_t)block_bytes, header.size() + file_off[b0], filename);
+            }
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            if (err.empty()) err = e.what();
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int g = 1; g < G; g++) threads.emplace_back(worker, g);
+    worker(0);
+    for (auto &t : threads) t.join();
+    if (!err.empty()) throw PfileError(err);
+    st.seconds_body = now_s() - t_body;
+    st.seconds_kernel = *std::max_element(kernel_s.begin(), kernel_s.end());
+    return st;
+}
+
+}  // namespace pgenhost

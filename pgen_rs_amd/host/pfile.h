@@ -1,0 +1,75 @@
+// pfile.h — C++ host restatement of pgen-rs's `Pfile` (src/pfile.rs:19-336) above the C ABI of
+// include/pgen_hip.h.  Same names and argument meaning as the reference so a pgen-rs user finds
+// what they expect; the per-variant decode/emit body (src/pfile.rs:165-190) is NOT here — it runs
+// on the GPU through pgenhip_emit_lines.  The reference is compiled Rust and no Rust toolchain
+// exists in this image, hence C++.
+#pragma once
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "csvlite.h"
+
+namespace pgenhost {
+
+// What the reference expresses as panic!/unwrap()/assert! (exit status 101).
+struct PfileError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+struct OutputOptions {
+    int n_gpus = 1;                         // variant ranges shard over devices 0..n_gpus-1 (no collective)
+    uint64_t block_text_bytes = 512ull << 20;  // VCF bytes produced per launch and device
+    bool verbose = false;
+};
+
+struct OutputStats {
+    uint64_t variants = 0, samples_kept = 0, header_bytes = 0, body_bytes = 0;
+    double seconds_filter = 0, seconds_body = 0, seconds_kernel = 0;
+};
+
+class Pfile {
+  public:
+    std::string pfile_prefix;  // src/pfile.rs:20-22
+    uint32_t num_variants = 0;
+    uint32_t num_samples = 0;
+
+    std::string pgen_path() const { return pfile_prefix + ".pgen"; }  // :26-36
+    std::string psam_path() const { return pfile_prefix + ".psam"; }
+    std::string pvar_path() const { return pfile_prefix + ".pvar"; }
+
+    // :38-76 — opens PREFIX.pgen and checks magic / storage mode 0x02 / flag byte 0x40
+    static Pfile from_prefix(const std::string &pfile_prefix);
+
+    // :196-200
+    uint32_t variant_record_size() const;
+
+    // :202-220 — (all leading '#' lines but the last, the last one = column names line)
+    std::pair<std::string, std::string> read_pvar_header() const;
+
+    // :248-268 — byte offset just after the '#' of the column-header line
+    static uint64_t find_metadata_file_header_start(const std::string &file_contents);
+
+    using IdxRecords = std::vector<std::pair<size_t, StringRecord>>;
+    // :312-335 — rows (file order) whose predicate is true; all rows without a query
+    static IdxRecords filter_metadata(TsvReader &reader, const std::optional<std::string> &query);
+
+    // :78-102 — prints f_string evaluated on each kept row to `out` (stdout in the CLI)
+    static void query_metadata(TsvReader &reader, const std::optional<std::string> &query, const std::string &f_string,
+                               std::string &out);
+
+    // :104-194 — header on the host, body lines assembled on the GPU(s)
+    OutputStats output_vcf(const std::optional<std::string> &sam_query, const std::optional<std::string> &var_query,
+                           const std::string &filename, const OutputOptions &opt = OutputOptions()) const;
+
+    // the header part of output_vcf (:110-146) on its own: used by output_vcf and by the CPU tests
+    std::string vcf_header(const IdxRecords &sam_idx_rcs, const StringRecord &sam_header) const;
+};
+
+// whole-file read helper (metadata files are read once; the reference streams them through BufReader)
+std::string read_file(const std::string &path);
+
+}  // namespace pgenhost
