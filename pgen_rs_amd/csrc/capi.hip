@@ -262,8 +262,16 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
     switch (which) {
         case PGENHIP_KERNEL_AUTO:
             if (ctx->subset) {
-                ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank};
-                HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
+                // measured crossover (profiles/r01_kernel_sweeps.md, probe16): with very sparse masks on long
+                // records the list gather touches only the kept samples' lines and wins; everywhere else the
+                // scan + LDS-compaction kernel does (it reads each record once with wide loads)
+                const bool very_sparse = ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 64ull <= ctx->sample_count;
+                if (very_sparse) {
+                    HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+                } else {
+                    ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank};
+                    HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
+                }
             } else if (gt_wide_applicable(a))
                 HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
             else if (gt_flat_applicable(a))

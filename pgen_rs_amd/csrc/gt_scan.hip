@@ -34,6 +34,7 @@ constexpr uint32_t kSegWords = kSegSamples / 64;        // 256 keep words
 constexpr uint32_t kTileSamples = 4096;                 // 64 lanes x 64 samples = 1 KiB of record
 constexpr uint32_t kTilesPerSeg = kSegSamples / kTileSamples;
 constexpr uint32_t kRing = 8192;                        // code ring per wave (bytes, power of two)
+constexpr uint32_t kFlushCodes = 2048;                  // pending codes that trigger a mid-segment flush (ring holds 2048 + 4096 + carry)
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
@@ -87,38 +88,66 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
     const uint32_t R = a.record_size;
     if (seg_cnt == 0u && !last_seg) return;                   // nothing of this segment is kept
 
-    for (uint64_t j = (uint64_t)row_group * kWaves + wave; j < a.n_variants; j += (uint64_t)row_groups * kWaves) {
-        const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[j] : j;
+    // the keep word and rank of this lane's 64 samples in each tile do not depend on the row:
+    // take them out of LDS once
+    uint64_t m[kTilesPerSeg];
+    uint32_t pre[kTilesPerSeg], tile_end[kTilesPerSeg];
+    uint32_t live_tiles = 0u;  // tiles with at least one kept sample (wave-uniform bit set)
+#pragma unroll
+    for (uint32_t t = 0; t < kTilesPerSeg; t++) {
+        m[t] = s_mask[t * 64u + lane];
+        pre[t] = s_pre[t * 64u + lane];
+        tile_end[t] = s_pre[t * 64u + 64u];
+        if (__ballot(m[t] != 0ull) != 0ull) live_tiles |= 1u << t;
+    }
+
+    const uint64_t row_step = (uint64_t)row_groups * kWaves;
+    uint64_t j = (uint64_t)row_group * kWaves + wave;
+    if (j >= a.n_variants) return;
+
+    // ---- coalesced wide loads of the packed 2-bit words: 16 B (64 samples) per lane and tile,
+    // all tiles of the segment in flight at once, and the NEXT row's requested before this row is
+    // processed (register double buffering)
+    v4u cur[kTilesPerSeg], nxt[kTilesPerSeg];
+    auto load_row = [&](uint64_t row, v4u(&dst)[kTilesPerSeg]) {
+        const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
         const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) {
+            dst[t] = v4u{0u, 0u, 0u, 0u};
+            const uint32_t b = seg_byte0 + t * 1024u + lane * 16u;
+            if (m[t] != 0ull) {
+                if (b + 16u <= R) {
+                    __builtin_memcpy(&dst[t], rec + b, 16);
+                } else {
+                    // record tail: only the bytes that exist (pad bits beyond N are masked out by m)
+                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+                    for (uint32_t q = 0; q < 16u && b + q < R; q++) w[q >> 2] |= (uint32_t)rec[b + q] << (8u * (q & 3u));
+                    dst[t] = v4u{w[0], w[1], w[2], w[3]};
+                }
+            }
+        }
+    };
+    load_row(j, cur);
+
+    for (;;) {
+        const uint64_t j_next = j + row_step;
+        const bool more = j_next < a.n_variants;
+        if (more) load_row(j_next, nxt);
+
         uint8_t *const row_out = a.out + j * a.out_stride;    // byte 0 of this row's GT segment
         const uint64_t row_addr = (uint64_t)(uintptr_t)row_out;
         uint64_t emitted = 4ull * seg_k0;                      // next row byte this wave must write
         uint32_t produced = 0u;                                // codes in the ring (rank relative to seg_k0)
 
+#pragma unroll
         for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
-            const uint32_t w = tile * 64u + lane;
-            const uint64_t m = s_mask[w];
-            const bool any = __ballot(m != 0ull) != 0ull;
-            if (any) {
-                // ---- coalesced wide load of the packed 2-bit words: 16 B (64 samples) per lane
-                const uint32_t b = seg_byte0 + tile * 1024u + lane * 16u;
-                uint64_t lo = 0ull, hi = 0ull;
-                if (m != 0ull) {
-                    if (b + 16u <= R) {
-                        v4u v;
-                        __builtin_memcpy(&v, rec + b, 16);
-                        lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
-                        hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-                    } else {
-                        for (uint32_t t = 0; t < 16u && b + t < R; t++) {
-                            const uint64_t byte = rec[b + t];
-                            if (t < 8u) lo |= byte << (8u * t); else hi |= byte << (8u * (t - 8u));
-                        }
-                    }
-                }
+            if (live_tiles & (1u << tile)) {
                 // ---- compaction: kept codes go to the ring at their rank (src/pfile.rs:171-175)
-                uint32_t pos = s_pre[w];
-                uint64_t mm = m;
+                const uint64_t lo = (uint64_t)cur[tile].x | ((uint64_t)cur[tile].y << 32);
+                const uint64_t hi = (uint64_t)cur[tile].z | ((uint64_t)cur[tile].w << 32);
+                uint32_t pos = pre[tile];
+                uint64_t mm = m[tile];
                 while (mm != 0ull) {
                     const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
                     mm &= mm - 1ull;
@@ -127,14 +156,16 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
                     pos++;
                 }
             }
-            produced = s_pre[tile * 64u + 64u];  // == prefix of the next tile's first word
+            produced = tile_end[tile];
             const bool final = tile + 1u == kTilesPerSeg || produced == seg_cnt;
+            // flush when the segment is done, or when enough text is pending to fill whole stores
+            const uint64_t avail = 4ull * ((uint64_t)seg_k0 + produced);
+            if (!final && avail - emitted < 4ull * kFlushCodes) continue;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // ---- flush: row bytes [emitted, hi_emit) are now determined
-            const uint64_t avail = 4ull * ((uint64_t)seg_k0 + produced);
             uint64_t hi_emit;
             if (final)
                 hi_emit = avail + (last_seg ? 1ull : 0ull);             // '\n' closes the row (:190)
@@ -148,29 +179,43 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
                     const uint64_t caddr = (c_first + i) << 4;
                     const int64_t q = (int64_t)(caddr - row_addr);      // row byte of the chunk start
                     uint8_t *dst = row_out + q;
-                    if (caddr >= lo_addr && caddr + 16ull <= hi_addr && (uint64_t)q + 16ull <= 4ull * K) {
-                        // interior: five consecutive kept codes from the ring
-                        const uint32_t rel = (uint32_t)((uint64_t)q >> 2) - seg_k0;
-                        const uint32_t sh = (uint32_t)q & 3u;
-                        const uint32_t t0 = gt_text(ring_code(ring, rel));
-                        const uint32_t t1 = gt_text(ring_code(ring, rel + 1u));
-                        const uint32_t t2 = gt_text(ring_code(ring, rel + 2u));
-                        const uint32_t t3 = gt_text(ring_code(ring, rel + 3u));
-                        const uint32_t t4 = gt_text(ring_code(ring, rel + 4u));
-                        v4u v = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
+                    // five consecutive kept codes from the ring (ranks outside this flush read stale
+                    // ring bytes: they only feed bytes that are masked out below)
+                    const int64_t k0s = q >> 2;                           // floor; may be < seg_k0 in the first chunk
+                    const uint32_t rel = (uint32_t)((int64_t)k0s - (int64_t)seg_k0);
+                    const uint32_t sh = (uint32_t)q & 3u;
+                    const uint32_t t0 = gt_text(ring_code(ring, rel));
+                    const uint32_t t1 = gt_text(ring_code(ring, rel + 1u));
+                    const uint32_t t2 = gt_text(ring_code(ring, rel + 2u));
+                    const uint32_t t3 = gt_text(ring_code(ring, rel + 3u));
+                    const uint32_t t4 = gt_text(ring_code(ring, rel + 4u));
+                    uint32_t d[4] = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
+                    // the row's '\n' (row byte 4K) if it falls into this chunk
+                    const int64_t nl = (int64_t)(4ull * K) - q;
+                    if (nl >= 0 && nl < 16) {
+#pragma unroll
+                        for (int mth = 0; mth < 4; mth++) {
+                            if ((nl >> 2) == mth) d[mth] = (d[mth] & ~(0xFFu << (8 * (nl & 3)))) | (0x0Au << (8 * (nl & 3)));
+                        }
+                    }
+                    // valid bytes of this chunk: [vb, ve) within 0..16
+                    const uint32_t vb = caddr >= lo_addr ? 0u : (uint32_t)(lo_addr - caddr);
+                    const uint32_t ve = caddr + 16ull <= hi_addr ? 16u : (uint32_t)(hi_addr - caddr);
+                    if (vb == 0u && ve == 16u) {
+                        v4u v = {d[0], d[1], d[2], d[3]};
                         *reinterpret_cast<v4u *>(dst) = v;
                     } else {
+                        // segment / row edge: whole dwords where possible, single bytes otherwise
 #pragma unroll
-                        for (int bb = 0; bb < 16; bb++) {
-                            const uint64_t addr = caddr + (uint64_t)bb;
-                            if (addr >= lo_addr && addr < hi_addr) {
-                                const uint64_t p = addr - row_addr;
-                                uint32_t ch;
-                                if (p == 4ull * K)
-                                    ch = '\n';
-                                else
-                                    ch = gt_text_byte(ring_code(ring, (uint32_t)(p >> 2) - seg_k0), (uint32_t)p & 3u);
-                                dst[bb] = (uint8_t)ch;
+                        for (int mth = 0; mth < 4; mth++) {
+                            const uint32_t b0 = 4u * mth;
+                            if (vb <= b0 && ve >= b0 + 4u) {
+                                *reinterpret_cast<uint32_t *>(dst + b0) = d[mth];
+                            } else {
+#pragma unroll
+                                for (int bb = 0; bb < 4; bb++) {
+                                    if (b0 + bb >= vb && b0 + bb < ve) dst[b0 + bb] = (uint8_t)(d[mth] >> (8 * bb));
+                                }
                             }
                         }
                     }
@@ -181,6 +226,10 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
             __builtin_amdgcn_wave_barrier();
             if (final) break;
         }
+        if (!more) break;
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) cur[t] = nxt[t];
+        j = j_next;
     }
 }
 

@@ -199,6 +199,18 @@ int main(int argc, char **argv)
             }
             return 0;
         }
+        if (cmd == "synth") {
+            // not in the reference: writes a synthetic PREFIX.{pgen,pvar,psam} triple of the SURVEY §8d shapes
+            // (records from the device generator pgenhip_synth_records; KEEP column = the 1-in-M keep mask)
+            Args a = parse(argc, argv, 2, {{"variants", 0}, {"samples", 0}, {"keep-modulus", 0}, {"seed", 0}}, {});
+            if (a.positional.size() != 1 || !a.has("variants") || !a.has("samples"))
+                usage_error("synth <PFILE_PREFIX> --variants <V> --samples <N> [--keep-modulus <M>] [--seed <S>]");
+            synth_pfile(a.positional[0], (uint32_t)std::strtoul(a.get("variants")->c_str(), nullptr, 10),
+                        (uint32_t)std::strtoul(a.get("samples")->c_str(), nullptr, 10),
+                        (uint32_t)std::strtoul(a.get("keep-modulus").value_or("100").c_str(), nullptr, 10),
+                        std::strtoull(a.get("seed").value_or("1346847054").c_str(), nullptr, 10));
+            return 0;
+        }
         usage_error("unrecognized subcommand '" + cmd + "'");
     } catch (const PfileError &e) {
         std::fprintf(stderr, "pgen-hip: %s\n", e.what());

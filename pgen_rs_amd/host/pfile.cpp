@@ -395,4 +395,58 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     return st;
 }
 
+
+namespace {
+uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+}  // namespace
+
+void synth_pfile(const std::string &prefix, uint32_t variants, uint32_t samples, uint32_t keep_modulus, uint64_t seed)
+{
+    const uint32_t R = pgenhip_variant_record_size(samples);
+    {
+        FILE *f = std::fopen((prefix + ".pvar").c_str(), "wb");
+        if (!f) throw PfileError("create " + prefix + ".pvar: " + std::strerror(errno));
+        std::fputs("##fileformat=VCFv4.2\n##source=pgen-hip synth\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n", f);
+        for (uint32_t i = 0; i < variants; i++) std::fprintf(f, "22\t%llu\tsnp%u\tA\tG\t100\tPASS\t.\n", 16050000ull + 7ull * i, i);
+        std::fclose(f);
+        f = std::fopen((prefix + ".psam").c_str(), "wb");
+        if (!f) throw PfileError("create " + prefix + ".psam: " + std::strerror(errno));
+        std::fputs("#IID\tSEX\tKEEP\n", f);
+        for (uint32_t i = 0; i < samples; i++)
+            std::fprintf(f, "S%06u\tNA\t%d\n", i, keep_modulus && splitmix64(0x4D41534Bull ^ (uint64_t)i) % keep_modulus == 0 ? 1 : 0);
+        std::fclose(f);
+    }
+    int fd = open((prefix + ".pgen").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) throw PfileError("create " + prefix + ".pgen: " + std::strerror(errno));
+    struct FdGuard {
+        int fd;
+        ~FdGuard() { close(fd); }
+    } guard{fd};
+    uint8_t hdr[12] = {0x6C, 0x1B, 0x02, 0, 0, 0, 0, 0, 0, 0, 0, 0x40};
+    for (int b = 0; b < 4; b++) {
+        hdr[3 + b] = (uint8_t)(variants >> (8 * b));
+        hdr[7 + b] = (uint8_t)(samples >> (8 * b));
+    }
+    pwrite_exact(fd, hdr, sizeof hdr, 0, prefix + ".pgen");
+    if (variants == 0 || R == 0) return;
+    DeviceBuffers B;
+    check(pgenhip_create(&B.ctx, 0, samples, nullptr, 0, 0), "pgenhip_create");
+    const uint64_t bv = std::max<uint64_t>(1, std::min<uint64_t>((256ull << 20) / R, variants));
+    check(pgenhip_host_malloc_pinned(B.ctx, &B.h_rec, (size_t)(bv * R)), "pinned records");
+    check(pgenhip_device_malloc(B.ctx, &B.d_rec, (size_t)(bv * R)), "device records");
+    for (uint64_t v0 = 0; v0 < variants; v0 += bv) {
+        const uint32_t nv = (uint32_t)std::min<uint64_t>(bv, variants - v0);
+        check(pgenhip_synth_records(B.ctx, B.d_rec, R, v0, nv, seed, 0), "pgenhip_synth_records");
+        check(pgenhip_memcpy_d2h(B.ctx, B.h_rec, B.d_rec, (size_t)nv * R), "D2H records");
+        check(pgenhip_wait(B.ctx), "pgenhip_wait");
+        pwrite_exact(fd, B.h_rec, (size_t)nv * R, 12ull + v0 * R, prefix + ".pgen");
+    }
+}
+
 }  // namespace pgenhost

@@ -69,6 +69,10 @@ class Pfile {
     std::string vcf_header(const IdxRecords &sam_idx_rcs, const StringRecord &sam_header) const;
 };
 
+// Synthetic PREFIX.{pgen,pvar,psam}: pvar rows "22\t{16050000+7i}\tsnp{i}\tA\tG\t100\tPASS\t.",
+// psam "#IID\tSEX\tKEEP" with "S{i:06d}\tNA\t{keep}", records from pgenhip_synth_records on device 0.
+void synth_pfile(const std::string &prefix, uint32_t variants, uint32_t samples, uint32_t keep_modulus, uint64_t seed);
+
 // whole-file read helper (metadata files are read once; the reference streams them through BufReader)
 std::string read_file(const std::string &path);
 
