@@ -73,8 +73,11 @@ uint64_t pgenhip_record_offset(uint64_t var_idx, uint32_t record_size);
 int pgenhip_create(pgenhip_ctx **ctx, int device_ordinal, uint32_t sample_count,
                    const uint32_t *kept_idx, uint32_t kept_count, uint32_t flags);
 int pgenhip_destroy(pgenhip_ctx *ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the ctx's own. NULL restores the own stream. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the ctx's own.
+ * NULL means HIP's default (null) stream — that IS torch's current stream unless a stream
+ * context is active.  pgenhip_reset_stream goes back to the ctx's own non-blocking stream. */
 int pgenhip_set_stream(pgenhip_ctx *ctx, void *hip_stream);
+int pgenhip_reset_stream(pgenhip_ctx *ctx);
 uint32_t pgenhip_sample_count(const pgenhip_ctx *ctx);
 uint32_t pgenhip_kept_count(const pgenhip_ctx *ctx);
 /* 4*K + 1: bytes one variant's GT segment occupies (src/pfile.rs:186-190) */

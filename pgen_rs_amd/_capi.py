@@ -54,6 +54,7 @@ PROTOTYPES = {
     "pgenhip_create": (C.c_int, [C.POINTER(ctx_p), C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
     "pgenhip_destroy": (C.c_int, [ctx_p]),
     "pgenhip_set_stream": (C.c_int, [ctx_p, C.c_void_p]),
+    "pgenhip_reset_stream": (C.c_int, [ctx_p]),
     "pgenhip_sample_count": (C.c_uint32, [ctx_p]),
     "pgenhip_kept_count": (C.c_uint32, [ctx_p]),
     "pgenhip_gt_row_bytes": (C.c_uint64, [ctx_p]),

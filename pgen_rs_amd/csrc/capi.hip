@@ -212,7 +212,14 @@ int pgenhip_destroy(pgenhip_ctx *ctx)
 int pgenhip_set_stream(pgenhip_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(PGENHIP_ERR_BAD_ARG, "ctx is NULL");
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);  // nullptr = the default (null) stream
+    return PGENHIP_OK;
+}
+
+int pgenhip_reset_stream(pgenhip_ctx *ctx)
+{
+    if (!ctx) return fail(PGENHIP_ERR_BAD_ARG, "ctx is NULL");
+    ctx->stream = ctx->own_stream;
     return PGENHIP_OK;
 }
 

@@ -104,7 +104,7 @@ class GtEngine:
         check(lib.pgenhip_set_stream(self._ctx, C.c_void_p(stream.cuda_stream)), "pgenhip_set_stream")
 
     def use_own_stream(self) -> None:
-        check(lib.pgenhip_set_stream(self._ctx, None), "pgenhip_set_stream")
+        check(lib.pgenhip_reset_stream(self._ctx), "pgenhip_reset_stream")
 
     def wait(self) -> None:
         check(lib.pgenhip_wait(self._ctx), "pgenhip_wait")

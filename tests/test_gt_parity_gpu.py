@@ -294,3 +294,34 @@ def test_wide_kernel_variants(monkeypatch, stream, nt):
     want = oracle.decode_emit(recs, len(vidx), n, variant_idx=vidx).reshape(len(vidx), -1)
     got, _ = run_engine(recs, len(vidx), n, kernel=_capi.KERNEL_WIDE, variant_idx=vidx)
     assert (got == expect_buffer(want, len(vidx), n, 4 * n + 1, 0, got.size)).all()
+
+
+def test_config3_full_size_100k_by_500k():
+    """BASELINE config 3 at its full size in ONE launch: 100 000 variants x 500 000 samples,
+    12.5 GB of records -> 200 GB of text (64-bit offsets everywhere).  Checked through
+    size-independent properties on the whole buffer (every row ends in LF at the right place,
+    TAB/slash columns on a strided sample) and byte equality with the oracle on rows picked from
+    the start, the u32-wrap boundary of the reference (34 359/34 360), the middle and the end."""
+    n, v = 500_000, 100_000
+    free, _total = torch.cuda.mem_get_info(0)
+    need = v * (125_000 + 4 * n + 1) + (2 << 30)
+    if free < need:
+        pytest.skip(f"needs {need / 2**30:.0f} GiB of free HBM, have {free / 2**30:.0f}")
+    row = 4 * n + 1
+    with pgen_rs_amd.GtEngine(n, device=0) as eng:
+        recs = eng.synth_records(v)
+        out = eng.decode_emit(recs, v)
+        eng.wait()
+        assert out.numel() == v * row
+        # every row's last byte is LF: strided view over the whole 200 GB
+        lf = out[row - 1 :: row]
+        assert lf.numel() == v and bool((lf == 10).all())
+        # first byte of every row is TAB
+        assert bool((out[0::row] == 9).all())
+        for j in (0, 1, 34_359, 34_360, 50_000, 99_998, 99_999):
+            got = out[j * row : (j + 1) * row].cpu().numpy()
+            host = recs[j * 125_000 : (j + 1) * 125_000].cpu().numpy()
+            assert got.tobytes() == oracle.decode_emit(host, 1, n).tobytes(), f"row {j}"
+            assert host.tobytes() == oracle.synth_records(n, 1, first_variant=j).tobytes()
+        del out, recs
+    torch.cuda.empty_cache()
