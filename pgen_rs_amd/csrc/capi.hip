@@ -23,6 +23,7 @@ struct pgenhip_ctx {
     uint32_t *d_kept = nullptr;
     uint64_t *d_keep_words = nullptr;  // scan kernel: keep bitmap, zero-padded to whole segments
     uint32_t *d_seg_rank = nullptr;    // scan kernel: kept samples before each segment
+    uint64_t *d_work = nullptr;        // stream kernel: per-XCD work-queue heads (8 x 128 B)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr;
@@ -161,6 +162,7 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
         ctx->stream = ctx->own_stream;
         if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) { rc = fail_hip(e, "hipEventCreate"); break; }
         if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) { rc = fail_hip(e, "hipEventCreate"); break; }
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_work), 8u * 128u)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(work counters)"); break; }
         if (ctx->subset) {
             size_t bytes = (size_t)(kept_count ? kept_count : 1u) * sizeof(uint32_t);
             if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_kept), bytes)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(kept_idx)"); break; }
@@ -201,6 +203,7 @@ int pgenhip_destroy(pgenhip_ctx *ctx)
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->d_kept) (void)hipFree(ctx->d_kept);
     if (ctx->d_keep_words) (void)hipFree(ctx->d_keep_words);
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_seg_rank) (void)hipFree(ctx->d_seg_rank);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -248,6 +251,7 @@ static int fill_args(pgenhip_ctx *ctx, EmitArgs &a, const void *d_records, uint6
     a.prefix_off = nullptr;
     a.line_off = nullptr;
     a.max_line_bytes = 0;
+    a.work_counters = ctx->d_work;
     return PGENHIP_OK;
 }
 

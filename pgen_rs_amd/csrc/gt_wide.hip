@@ -19,6 +19,7 @@
 // (register double-buffering), so loads stay in flight behind the store stream.
 // The chunk that holds a row's '\n' also holds the head of row j+1: its first bytes come from a
 // direct byte load (one lane per row).  Stream head/tail chunks use masked byte stores.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "gt_common.hip.h"
@@ -40,6 +41,7 @@ struct WideParams {
     uint64_t n_items;        // V * spans_per_row
     uint32_t spans_per_row;
     uint32_t head;           // out address & 127: the chunk grid is anchored at a 128-B line boundary
+    uint64_t *dbg;           // diagnostic builds only (PGENHIP_DEBUG_TIMES=1): per-wave {start, end, items} stamps, else nullptr
 };
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -212,6 +214,9 @@ __global__ __launch_bounds__(kThreads) void gt_wide_kernel(EmitArgs a, WideParam
 
     uint64_t t = (uint64_t)blockIdx.x * kWaves + wave;
     if (t >= p.n_items) return;
+    const uint64_t dbg_slot = ((uint64_t)blockIdx.x * kWaves + wave) * 3ull;
+    uint64_t dbg_items = 0;
+    if (p.dbg && lane == 0u) p.dbg[dbg_slot] = __builtin_amdgcn_s_memrealtime();
 
     Item cur = make_item<HAS_VIDX>(a, p, t);
     v4u in0 = {0u, 0u, 0u, 0u}, in1 = {0u, 0u, 0u, 0u};
@@ -237,11 +242,16 @@ __global__ __launch_bounds__(kThreads) void gt_wide_kernel(EmitArgs a, WideParam
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         emit_item<HAS_VIDX, NT, false>(a, p, cur, slab, lane);
+        dbg_items++;
         if (!more) break;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         cur = nxt;
         t = t_next;
+    }
+    if (p.dbg && lane == 0u) {
+        p.dbg[dbg_slot + 1] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[dbg_slot + 2] = dbg_items;
     }
 }
 
@@ -350,6 +360,108 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, Wi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gt_stream_dyn_kernel — gt_stream_kernel with a WORK QUEUE instead of a static item partition.
+// Only ~3 of these 512-thread blocks fit on a CU, so a static grid-stride split of a big grid runs
+// in rounds and the last, partly filled round is a tail of several hundred microseconds on a
+// 2.4 ms launch (measured with per-wave s_memrealtime stamps).  Here the items are cut into 8
+// contiguous ranges (one per XCD, picked by blockIdx & 7 — placement is a speed hint only); the
+// loader wave claims NS consecutive items per step with one returning atomicAdd on its range's
+// head word (heads live 128 B apart; ~10 claims/us per word, far below the ~88/us a word takes)
+// and steals from the next range when its own is drained.  Every block therefore runs until the
+// whole launch is out of work and all of them finish within one step of each other.
+template <int NS, bool HAS_VIDX, bool NT>
+__global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a, WideParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][kRingSlots][kSlabBytes + kSlabExtra];
+    __shared__ uint32_t s_full[NS][kRingSlots];
+    __shared__ uint32_t s_done[NS][kRingSlots];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < NS * kRingSlots) {
+        (&s_full[0][0])[threadIdx.x] = 0u;
+        (&s_done[0][0])[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    constexpr uint64_t kNoItem = ~0ull;
+
+    if (wave == 0u) {
+        // ------------------------------ loader wave ------------------------------
+        const uint64_t per_range = (p.n_items + 7ull) / 8ull;
+        uint32_t range = blockIdx.x & 7u;
+        uint32_t drained = 0u;  // consecutive ranges found empty
+        for (uint64_t step = 0;; step++) {
+            // ---- claim NS consecutive items (lane 0 asks, the wave shares the answer)
+            uint64_t t0 = kNoItem;
+            while (drained < 8u) {
+                const uint64_t lo = (uint64_t)range * per_range;
+                const uint64_t hi = min(lo + per_range, p.n_items);
+                uint64_t got = 0;
+                if (lane == 0u) got = atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counters + range * 16u), (unsigned long long)NS);
+                got = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(got >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)got);
+                if (lo + got < hi) {
+                    t0 = lo + got;
+                    break;
+                }
+                range = (range + 1u) & 7u;  // own range drained: steal from the next one
+                drained++;
+            }
+            const uint64_t t_end = t0 == kNoItem ? 0ull : min(t0 + NS, min(((uint64_t)range + 1ull) * per_range, p.n_items));
+            const uint32_t slot = (uint32_t)(step % kRingSlots);
+            v4u in0[NS], in1[NS];
+            uint32_t nb[NS];
+#pragma unroll
+            for (int w = 0; w < NS; w++) {
+                const uint64_t t = t0 == kNoItem ? kNoItem : t0 + (uint64_t)w;
+                nb[w] = 0u;
+                in0[w] = v4u{0u, 0u, 0u, 0u};
+                in1[w] = v4u{0u, 0u, 0u, 0u};
+                if (t0 != kNoItem && t < t_end) {
+                    const Item it = make_item<HAS_VIDX>(a, p, t);
+                    if (lane < it.n_load) in0[w] = *reinterpret_cast<const v4u *>(it.base + lane * 16u);
+                    if (lane + 64u < it.n_load) in1[w] = *reinterpret_cast<const v4u *>(it.base + (lane + 64u) * 16u);
+                    const bool row_tail = it.cnt != 0u && it.c_first + 16ll * (int64_t)it.cnt >= (int64_t)p.row_bytes;
+                    if (row_tail && it.row + 1ull < a.n_variants && lane == 0u)
+                        nb[w] = (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < NS; w++) {
+                if (step >= (uint64_t)kRingSlots) {
+                    const uint32_t want = (uint32_t)(step - kRingSlots) + 1u;
+                    while (lds_flag_read(lds_offset(&s_done[w][slot])) != want) __builtin_amdgcn_s_sleep(1);
+                }
+                uint8_t *slab = slabs[w][slot];
+                const uint64_t t = (t0 != kNoItem && t0 + (uint64_t)w < t_end) ? t0 + (uint64_t)w : kNoItem;
+                *reinterpret_cast<v4u *>(slab + lane * 16u) = in0[w];
+                if (lane < 4u) *reinterpret_cast<v4u *>(slab + (lane + 64u) * 16u) = in1[w];
+                if (lane == 0u) {
+                    slab[kSlabBytes] = (uint8_t)nb[w];
+                    *reinterpret_cast<uint64_t *>(slab + kSlabBytes + 8u) = t0 == kNoItem ? kNoItem - 1ull : t;  // ~0-1 = "launch is out of work"
+                }
+                if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), (uint32_t)step + 1u);
+            }
+            if (t0 == kNoItem) break;
+        }
+    } else {
+        // ------------------------------ storer waves -----------------------------
+        const uint32_t w = wave - 1u;
+        for (uint64_t step = 0;; step++) {
+            const uint32_t slot = (uint32_t)(step % kRingSlots);
+            while (lds_flag_read(lds_offset(&s_full[w][slot])) != (uint32_t)step + 1u) __builtin_amdgcn_s_sleep(1);
+            const uint8_t *slab = slabs[w][slot];
+            uint64_t t = *reinterpret_cast<const uint64_t *>(slab + kSlabBytes + 8u);
+            t = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)t);
+            if (t == kNoItem - 1ull) break;          // the loader found every range drained
+            if (t != kNoItem) {                       // kNoItem: this storer has no item in this (last) step of a range
+                const Item it = make_item<HAS_VIDX>(a, p, t);
+                emit_item<HAS_VIDX, NT, true>(a, p, it, slab, lane);
+            }
+            if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), (uint32_t)step + 1u);
+        }
+    }
+}
+
 }  // namespace
 
 bool gt_wide_applicable(const EmitArgs &a)
@@ -366,6 +478,7 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
     p.row_bytes = 4ull * a.kept_count + 1ull;
     p.total_bytes = (uint64_t)a.n_variants * p.row_bytes;
     p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 127ull);
+    p.dbg = nullptr;
     // a row owns floor(S/16) or ceil(S/16) chunks (one more for row 0 with an unaligned pointer), and
     // its first span starts up to 63 chunks before them (1-KiB-aligned span grid)
     const uint64_t max_row_chunks = (p.row_bytes + 15ull) / 16ull + 1ull + 63ull;
@@ -378,6 +491,21 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
     const bool nt = en ? atoi(en) != 0 : true;
     const char *es = getenv("PGENHIP_WIDE_STREAM");  // 0 = symmetric waves, 3 / 7 = storer waves per block
     const int stream_ns = es ? atoi(es) : 7;  // default: 1 loader + 7 storer waves (interleaved A/B: profiles/r01_kernel_sweeps.md)
+    const char *ed = getenv("PGENHIP_WIDE_DYN");
+    const bool dyn = ed ? atoi(ed) != 0 : true;  // work queue on by default (interleaved A/B: +9 % on the chr22 block)
+    if (stream_ns == 7 && dyn && a.work_counters) {
+        hipError_t me = hipMemsetAsync(a.work_counters, 0, 8u * 128u, stream);
+        if (me != hipSuccess) return me;
+        const uint64_t need = (p.n_items + 6ull) / 7ull;
+        // 3 of these 512-thread blocks are resident per CU (78 VGPRs -> 6 waves/SIMD): launch exactly that many
+        const uint64_t cap = (uint64_t)num_cus * (uint64_t)(eb ? blocks_per_cu : 3);
+        const uint32_t g = (uint32_t)(need < cap ? need : cap);
+        void (*dk)(EmitArgs, WideParams);
+        if (a.variant_idx) dk = nt ? gt_stream_dyn_kernel<7, true, true> : gt_stream_dyn_kernel<7, true, false>;
+        else dk = nt ? gt_stream_dyn_kernel<7, false, true> : gt_stream_dyn_kernel<7, false, false>;
+        hipLaunchKernelGGL(dk, dim3(g), dim3(512), 0, stream, a, p);
+        return hipGetLastError();
+    }
     if (stream_ns == 3 || stream_ns == 7) {
         const uint64_t need = (p.n_items + (uint64_t)stream_ns - 1ull) / (uint64_t)stream_ns;
         const uint64_t cap = (uint64_t)num_cus * (uint64_t)blocks_per_cu;
@@ -401,6 +529,44 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
         kern = nt ? gt_wide_kernel<true, true> : gt_wide_kernel<true, false>;
     else
         kern = nt ? gt_wide_kernel<false, true> : gt_wide_kernel<false, false>;
+    // diagnostic only: per-wave start/end stamps dumped to /tmp/pgenhip_times.bin (never set in normal runs)
+    static const bool dbg_on = getenv("PGENHIP_DEBUG_TIMES") != nullptr;
+    if (dbg_on) {
+        const size_t words = (size_t)grid * kWaves * 3u;
+        uint64_t *d = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&d), words * 8u) == hipSuccess) {
+            (void)hipMemsetAsync(d, 0, words * 8u, stream);
+            p.dbg = d;
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipStreamSynchronize(stream);
+            (void)hipEventRecord(e0, stream);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, p);
+            (void)hipEventRecord(e1, stream);
+            (void)hipStreamSynchronize(stream);
+            float ev_ms = 0.f;
+            (void)hipEventElapsedTime(&ev_ms, e0, e1);
+            uint64_t *h = static_cast<uint64_t *>(malloc(words * 8u));
+            (void)hipMemcpy(h, d, words * 8u, hipMemcpyDeviceToHost);
+            uint64_t tmin = ~0ull, tmax = 0ull;
+            for (size_t i = 0; i < words; i += 3) {
+                if (h[i] == 0) continue;
+                if (h[i] < tmin) tmin = h[i];
+                if (h[i + 1] > tmax) tmax = h[i + 1];
+            }
+            fprintf(stderr, "[pgenhip dbg] grid %u: hipEvent %.1f us, first-wave-start..last-wave-end %.1f us\n", grid, ev_ms * 1e3, (double)(tmax - tmin) / 100.0);
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            if (FILE *f = fopen("/tmp/pgenhip_times.bin", "wb")) {
+                fwrite(h, 8, words, f);
+                fclose(f);
+            }
+            free(h);
+            (void)hipFree(d);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, p);
     return hipGetLastError();
 }

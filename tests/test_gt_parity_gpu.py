@@ -273,12 +273,14 @@ def test_large_shape_properties_config3_rows():
     assert rows.tobytes() == oracle.decode_emit(host, v, n).tobytes()
 
 
-@pytest.mark.parametrize("stream,nt", [(0, 0), (0, 1), (3, 0), (3, 1), (7, 0), (7, 1)])
-def test_wide_kernel_variants(monkeypatch, stream, nt):
-    """Every build of the wide kernel (symmetric waves / 1 loader + 3 or 7 storer waves, plain or
-    nontemporal stores) against the oracle, on shapes with 1 and several spans per row."""
+@pytest.mark.parametrize("stream,nt,dyn", [(0, 0, 0), (0, 1, 0), (3, 0, 0), (3, 1, 0), (7, 0, 0), (7, 1, 0), (7, 0, 1), (7, 1, 1)])
+def test_wide_kernel_variants(monkeypatch, stream, nt, dyn):
+    """Every build of the wide kernel (symmetric waves / 1 loader + 3 or 7 storer waves, static
+    partition or work queue, plain or nontemporal stores) against the oracle, on shapes with 1 and
+    several spans per row."""
     monkeypatch.setenv("PGENHIP_WIDE_STREAM", str(stream))
     monkeypatch.setenv("PGENHIP_WIDE_NT", str(nt))
+    monkeypatch.setenv("PGENHIP_WIDE_DYN", str(dyn))
     monkeypatch.setenv("PGENHIP_WIDE_BLOCKS_PER_CU", "2")
     rng = np.random.default_rng(500 + stream * 2 + nt)
     for n, v, off in [(2504, 301, 0), (1024, 77, 5), (4099, 40, 0), (40001, 9, 3), (70001, 5, 0)]:
