@@ -122,6 +122,10 @@ int pgenhip_wait(pgenhip_ctx *ctx);
 /* hipEvent pair on the ctx stream: start ... launches ... stop -> elapsed ms (stop synchronises). */
 int pgenhip_timer_start(pgenhip_ctx *ctx);
 int pgenhip_timer_stop(pgenhip_ctx *ctx, float *elapsed_ms);
+/* Pipelined form: mark records the stop event without blocking; read returns the elapsed ms once
+ * the stream has passed the mark (e.g. after pgenhip_wait). */
+int pgenhip_timer_mark(pgenhip_ctx *ctx);
+int pgenhip_timer_read(pgenhip_ctx *ctx, float *elapsed_ms);
 
 /* ---- device / pinned memory for hosts that do not link HIP themselves --- */
 int pgenhip_device_malloc(pgenhip_ctx *ctx, void **d_ptr, size_t bytes);

@@ -63,6 +63,8 @@ PROTOTYPES = {
     "pgenhip_wait": (C.c_int, [ctx_p]),
     "pgenhip_timer_start": (C.c_int, [ctx_p]),
     "pgenhip_timer_stop": (C.c_int, [ctx_p, C.POINTER(C.c_float)]),
+    "pgenhip_timer_mark": (C.c_int, [ctx_p]),
+    "pgenhip_timer_read": (C.c_int, [ctx_p, C.POINTER(C.c_float)]),
     "pgenhip_device_malloc": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "pgenhip_device_free": (C.c_int, [ctx_p, C.c_void_p]),
     "pgenhip_host_malloc_pinned": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.c_size_t]),

@@ -362,6 +362,23 @@ int pgenhip_timer_stop(pgenhip_ctx *ctx, float *elapsed_ms)
     return PGENHIP_OK;
 }
 
+int pgenhip_timer_mark(pgenhip_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    return PGENHIP_OK;
+}
+
+int pgenhip_timer_read(pgenhip_ctx *ctx, float *elapsed_ms)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!elapsed_ms) return fail(PGENHIP_ERR_BAD_ARG, "elapsed_ms is NULL");
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+    return PGENHIP_OK;
+}
+
 int pgenhip_device_malloc(pgenhip_ctx *ctx, void **d_ptr, size_t bytes)
 {
     int rc = bind(ctx);
