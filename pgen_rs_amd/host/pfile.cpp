@@ -305,7 +305,8 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     int n_dev = 0;
     check(pgenhip_device_count(&n_dev), "pgenhip_device_count");
     if (n_dev <= 0) throw PfileError("no HIP device: the GT decode/emit path has no CPU fallback");
-    const int G = std::max(1, std::min(opt.n_gpus, n_dev));
+    const int n_use = std::max(1, std::min(opt.n_gpus, n_dev));      // devices actually used
+    const int G = opt.n_shards > 0 ? opt.n_shards : n_use;            // variant ranges (shards)
     const double t_body = now_s();
     std::mutex err_mu;
     std::string err;
@@ -341,7 +342,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
             DeviceBuffers sets[2];
             for (int s = 0; s < n_sets; s++) {
                 DeviceBuffers &B = sets[s];
-                check(pgenhip_create(&B.ctx, g, N, all_samples ? nullptr : kept.data(), (uint32_t)K, 0), "pgenhip_create");
+                check(pgenhip_create(&B.ctx, g % n_use, N, all_samples ? nullptr : kept.data(), (uint32_t)K, 0), "pgenhip_create");
                 check(pgenhip_host_malloc_pinned(B.ctx, &B.h_rec, rec_bytes), "pinned records");
                 check(pgenhip_host_malloc_pinned(B.ctx, &B.h_blob, blob_bytes), "pinned prefixes");
                 check(pgenhip_host_malloc_pinned(B.ctx, &B.h_off, off_bytes), "pinned offsets");

@@ -22,6 +22,7 @@ struct PfileError : std::runtime_error {
 
 struct OutputOptions {
     int n_gpus = 1;                         // variant ranges shard over devices 0..n_gpus-1 (no collective)
+    int n_shards = 0;                       // 0 = one shard per GPU; > 0: that many variant ranges, dealt round-robin over the GPUs
     uint64_t block_text_bytes = 512ull << 20;  // VCF bytes produced per launch and device
     int write_threads = 1;                  // parallel pwrite()s per block and device
     bool verbose = false;
