@@ -94,6 +94,7 @@ def main() -> int:
     ap.add_argument("--keep-modulus", type=int, default=0, help="keep sample i iff splitmix64(seed^i) %% m == 0 (0 = all)")
     ap.add_argument("--cpu-sample-variants", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", type=int, default=0, help="PGENHIP_KERNEL_* override for A/B runs (0 = automatic, the measured default)")
     args = ap.parse_args()
 
     import torch
@@ -130,7 +131,7 @@ def main() -> int:
     out = torch.empty(v * eng.gt_row_bytes, dtype=torch.uint8, device=dev)
 
     def step() -> None:
-        eng.decode_emit(recs, v, out=out)
+        eng.decode_emit(recs, v, out=out, kernel=args.kernel)
 
     for _ in range(args.warmup):
         step()

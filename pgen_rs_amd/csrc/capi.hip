@@ -273,11 +273,11 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
     switch (which) {
         case PGENHIP_KERNEL_AUTO:
             if (ctx->subset) {
-                // measured crossover (profiles/r01_kernel_sweeps.md, probe16): with very sparse masks on long
+                // measured crossover (profiles/r01_kernel_sweeps.md, probe17: scan wins at 1 % kept, the gather at 0.1 %): with very sparse masks on long
                 // records the list gather touches only the kept samples' lines and wins; everywhere else the
                 // scan + LDS-compaction kernel does (it reads each record once with wide loads)
-                const bool very_sparse = ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 64ull <= ctx->sample_count;
-                if (very_sparse) {
+                const bool very_sparse = ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 128ull <= ctx->sample_count;
+                if (very_sparse || ctx->record_size < 16u) {
                     HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
                 } else {
                     ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank};
@@ -295,6 +295,7 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
             return PGENHIP_OK;
         case PGENHIP_KERNEL_SCAN: {
             if (!ctx->subset) return fail(PGENHIP_ERR_BAD_ARG, "scan kernel needs a kept-sample list");
+            if (ctx->record_size < 16u) return fail(PGENHIP_ERR_BAD_ARG, "scan kernel needs N >= 61 (records of >= 16 bytes)");
             ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank};
             HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;

@@ -109,23 +109,23 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
     // all tiles of the segment in flight at once, and the NEXT row's requested before this row is
     // processed (register double buffering)
     v4u cur[kTilesPerSeg], nxt[kTilesPerSeg];
+    // Branch-free: every lane always loads 16 bytes from inside the record (R >= 16 is a launch
+    // precondition).  A window that would run past the record end (last lane of the last tile) is
+    // pulled back to R-16 and the bytes are shifted into place at use time (`tail_shift`), so no
+    // conditional byte loop — and with it no early s_waitcnt — sits between the loads.
+    uint32_t tail_shift[kTilesPerSeg];
+#pragma unroll
+    for (uint32_t t = 0; t < kTilesPerSeg; t++) {
+        const uint32_t b = seg_byte0 + t * 1024u + lane * 16u;
+        tail_shift[t] = b + 16u <= R ? 0u : min(b - (R - 16u), 16u);
+    }
     auto load_row = [&](uint64_t row, v4u(&dst)[kTilesPerSeg]) {
         const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
         const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
 #pragma unroll
         for (uint32_t t = 0; t < kTilesPerSeg; t++) {
-            dst[t] = v4u{0u, 0u, 0u, 0u};
-            const uint32_t b = seg_byte0 + t * 1024u + lane * 16u;
-            if (m[t] != 0ull) {
-                if (b + 16u <= R) {
-                    __builtin_memcpy(&dst[t], rec + b, 16);
-                } else {
-                    // record tail: only the bytes that exist (pad bits beyond N are masked out by m)
-                    uint32_t w[4] = {0u, 0u, 0u, 0u};
-                    for (uint32_t q = 0; q < 16u && b + q < R; q++) w[q >> 2] |= (uint32_t)rec[b + q] << (8u * (q & 3u));
-                    dst[t] = v4u{w[0], w[1], w[2], w[3]};
-                }
-            }
+            const uint32_t b = min(seg_byte0 + t * 1024u + lane * 16u, R - 16u);
+            __builtin_memcpy(&dst[t], rec + b, 16);
         }
     };
     load_row(j, cur);
@@ -133,6 +133,11 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
     for (;;) {
         const uint64_t j_next = j + row_step;
         const bool more = j_next < a.n_variants;
+        // gfx9 has ONE in-order vmcnt: make this row's words land before the next row's are
+        // requested (they were issued a whole row ago, so this wait is short), otherwise the first
+        // use of `cur` below would also wait for the loads issued here
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) asm volatile("" ::"v"(cur[t].x), "v"(cur[t].y), "v"(cur[t].z), "v"(cur[t].w));
         if (more) load_row(j_next, nxt);
 
         uint8_t *const row_out = a.out + j * a.out_stride;    // byte 0 of this row's GT segment
@@ -144,8 +149,15 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
         for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
             if (live_tiles & (1u << tile)) {
                 // ---- compaction: kept codes go to the ring at their rank (src/pfile.rs:171-175)
-                const uint64_t lo = (uint64_t)cur[tile].x | ((uint64_t)cur[tile].y << 32);
-                const uint64_t hi = (uint64_t)cur[tile].z | ((uint64_t)cur[tile].w << 32);
+                uint64_t lo = (uint64_t)cur[tile].x | ((uint64_t)cur[tile].y << 32);
+                uint64_t hi = (uint64_t)cur[tile].z | ((uint64_t)cur[tile].w << 32);
+                if (tail_shift[tile] != 0u) {
+                    // record tail: the window was pulled back by tail_shift bytes; drop them
+                    const uint32_t sh8 = tail_shift[tile] * 8u;
+                    if (sh8 >= 128u) { lo = 0ull; hi = 0ull; }
+                    else if (sh8 >= 64u) { lo = hi >> (sh8 - 64u); hi = 0ull; }
+                    else { lo = (lo >> sh8) | (hi << (64u - sh8)); hi >>= sh8; }
+                }
                 uint32_t pos = pre[tile];
                 uint64_t mm = m[tile];
                 while (mm != 0ull) {

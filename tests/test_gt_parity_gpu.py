@@ -28,7 +28,7 @@ def kernels_for(subset: bool, dense: bool, n: int = 0):
         ks.append(_capi.KERNEL_FLAT)
     if not subset and dense and n >= 1024:
         ks.append(_capi.KERNEL_WIDE)
-    if subset:
+    if subset and n >= 61:  # the scan kernel needs records of >= 16 bytes
         ks.append(_capi.KERNEL_SCAN)
     return ks
 
@@ -160,7 +160,7 @@ def test_kept_subsets_vs_oracle(n):
     recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
     for label, kept in keep_lists(n, rng):
         want = oracle.decode_emit(recs, v, n, kept_idx=kept).reshape(v, -1)
-        for kern in kernels_for(True, True):
+        for kern in kernels_for(True, True, n):
             got, k = run_engine(recs, v, n, kept=kept, kernel=kern)
             assert k == kept.size
             exp = expect_buffer(want, v, k, 4 * k + 1, 0, got.size)
@@ -178,7 +178,7 @@ def test_subset_with_strides_offsets_and_gather():
     dense = np.concatenate([recs[5 + i * rstride : 5 + i * rstride + r] for i in range(vfile)])
     want = oracle.decode_emit(dense, len(vidx), n, kept_idx=kept, variant_idx=vidx).reshape(len(vidx), -1)
     k = kept.size
-    for kern in kernels_for(True, False):
+    for kern in kernels_for(True, False, n):
         got, _ = run_engine(recs, len(vidx), n, kept=kept, kernel=kern, record_stride=rstride, out_stride=4 * k + 1 + 6,
                             variant_idx=vidx, out_offset=3, records_offset=5)
         exp = expect_buffer(want, len(vidx), k, 4 * k + 1 + 6, 3, got.size)
