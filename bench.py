@@ -94,6 +94,9 @@ def main() -> int:
     ap.add_argument("--keep-modulus", type=int, default=0, help="keep sample i iff splitmix64(seed^i) %% m == 0 (0 = all)")
     ap.add_argument("--cpu-sample-variants", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N>1 path)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (with --dist-backend gloo) so the N>1 code path can run on a 1-GPU box")
     ap.add_argument("--kernel", type=int, default=0, help="PGENHIP_KERNEL_* override for A/B runs (0 = automatic, the measured default)")
     args = ap.parse_args()
 
@@ -111,11 +114,17 @@ def main() -> int:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the timing reduction lives
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     n, v = args.samples, args.variants
     kept = None
@@ -150,7 +159,7 @@ def main() -> int:
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
 
-    t_all = torch.tensor([dt, event_ms], dtype=torch.float64, device=dev)
+    t_all = torch.tensor([dt, event_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     dt_max, event_ms_max = float(t_all[0]), float(t_all[1])
