@@ -43,7 +43,9 @@ __device__ __forceinline__ uint32_t ring_code(const uint8_t *ring, uint32_t rel)
     return ring[rel & (kRing - 1u)];
 }
 
-template <bool HAS_VIDX>
+// DENSE: most samples are kept (host decides from K/N): compact one record byte (4 samples) per step
+// instead of one kept sample per step.  A separate instantiation keeps the sparse build's registers low.
+template <bool HAS_VIDX, bool DENSE>
 __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups)
 {
     __shared__ uint64_t s_mask[kSegWords];
@@ -160,12 +162,44 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
                 }
                 uint32_t pos = pre[tile];
                 uint64_t mm = m[tile];
-                while (mm != 0ull) {
-                    const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
-                    mm &= mm - 1ull;
-                    const uint64_t half = bit < 32u ? lo : hi;
-                    ring[pos & (kRing - 1u)] = (uint8_t)((half >> ((bit & 31u) * 2u)) & 3ull);
-                    pos++;
+                if (DENSE) {
+                    // dense masks: one record byte (4 samples) at a time; a fully kept byte becomes
+                    // one 4-byte ring write (codes spread to one per byte), partial bytes go bit-wise
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const uint32_t nib = (uint32_t)(mm >> (4 * q)) & 0xFu;
+                        if (nib == 0u) continue;
+                        const uint32_t x = (uint32_t)((q < 8 ? lo : hi) >> (8 * (q & 7))) & 0xFFu;
+                        if (nib == 0xFu) {
+                            const uint32_t d = (x & 3u) | ((x & 0xCu) << 6) | ((x & 0x30u) << 12) | ((x & 0xC0u) << 18);
+                            const uint32_t idx = pos & (kRing - 1u);
+                            if (idx <= kRing - 4u) {
+                                __builtin_memcpy(ring + idx, &d, 4);
+                            } else {
+                                ring[idx] = (uint8_t)d;
+                                ring[(idx + 1u) & (kRing - 1u)] = (uint8_t)(d >> 8);
+                                ring[(idx + 2u) & (kRing - 1u)] = (uint8_t)(d >> 16);
+                                ring[(idx + 3u) & (kRing - 1u)] = (uint8_t)(d >> 24);
+                            }
+                            pos += 4u;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                if (nib & (1u << e)) {
+                                    ring[pos & (kRing - 1u)] = (uint8_t)((x >> (2 * e)) & 3u);
+                                    pos++;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    while (mm != 0ull) {
+                        const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
+                        mm &= mm - 1ull;
+                        const uint64_t half = bit < 32u ? lo : hi;
+                        ring[pos & (kRing - 1u)] = (uint8_t)((half >> ((bit & 31u) * 2u)) & 3ull);
+                        pos++;
+                    }
                 }
             }
             produced = tile_end[tile];
@@ -257,7 +291,12 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hi
     if (groups < 1ull) groups = 1ull;
     if (groups > groups_needed) groups = groups_needed;
     const uint32_t grid = (uint32_t)(groups * n_seg_eff);
-    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t) = a.variant_idx ? gt_scan_kernel<true> : gt_scan_kernel<false>;
+    const bool dense = (uint64_t)a.kept_count * 4ull > (uint64_t)a.sample_count * 3ull;  // > 75 % kept
+    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t);
+    if (a.variant_idx)
+        kern = dense ? gt_scan_kernel<true, true> : gt_scan_kernel<true, false>;
+    else
+        kern = dense ? gt_scan_kernel<false, true> : gt_scan_kernel<false, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, sc, n_seg_eff, (uint32_t)groups);
     return hipGetLastError();
 }
