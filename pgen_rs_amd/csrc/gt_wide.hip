@@ -33,7 +33,13 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr uint32_t kSpanChunks = 1024;  // chunks per work item: 16 stores x 64 lanes
 constexpr uint32_t kSlabBytes = 1088;   // 66 lanes x 16 B staged at most, rounded to 64
-constexpr uint32_t kSlabExtra = 16;     // stream kernel: first byte of the next row rides behind the slab
+constexpr uint32_t kSlabExtra = 16;     // stream kernels: +0 u8 = first record byte of row j+1 (for the chunk holding row j's '\n')
+// Item descriptors travel in their own LDS ring (kDescSlots = ring slots + 1 per storer, 64 B each), so the
+// loader can write them while it issues the loads, before it has to wait for the slab slot to be free:
+//   +8  u64 item index t (work-queue kernel; ~0 = no item, ~0-1 = launch is out of work)
+//   +16 u64 g0   +24 i64 c_first   +32 u64 row   +40 u32 cnt   +44 u32 lead   +48 i32 delta
+// and a storer wave does not redo the loader's 64-bit scalar item arithmetic.
+constexpr uint32_t kDescBytes = 64;
 
 struct WideParams {
     uint64_t row_bytes;      // S = 4N + 1
@@ -72,6 +78,7 @@ struct Item {
     const uint8_t *rec;   // record of row j
     const uint8_t *base;  // 16-B-aligned address the staged bytes start at
     uint32_t n_load;      // 16-byte pieces to stage (<= 66)
+    int32_t delta;        // slab offset of record byte 0 (= rec - base)
     uint64_t row;         // j
 };
 
@@ -104,6 +111,45 @@ __device__ __forceinline__ Item make_item(const EmitArgs &a, const WideParams &p
     const uint32_t mis = (uint32_t)(addr_first & 15ull);
     it.base = it.rec + b_first - mis;
     it.n_load = it.cnt ? (mis + (b_last - b_first)) / 16u + 1u : 0u;
+    it.delta = (int32_t)mis - (int32_t)b_first;
+    return it;
+}
+
+
+// ---- item descriptor hand-over through the slab's extra area (layout at kSlabExtra) ----------
+// NB: __builtin_amdgcn_readfirstlane returns a signed int — widen through uint32_t, or a low half
+// with bit 31 set sign-extends into the high half (found by the full-size config-3 test: g0 >= 2^31)
+__device__ __forceinline__ uint32_t sgpr32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t sgpr64(uint64_t v)
+{
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+
+__device__ __forceinline__ void desc_put_item(uint8_t *x, const Item &it, uint64_t t)
+{
+    *reinterpret_cast<uint64_t *>(x + 8) = t;
+    *reinterpret_cast<uint64_t *>(x + 16) = it.g0;
+    *reinterpret_cast<int64_t *>(x + 24) = it.c_first;
+    *reinterpret_cast<uint64_t *>(x + 32) = it.row;
+    *reinterpret_cast<uint32_t *>(x + 40) = it.cnt;
+    *reinterpret_cast<uint32_t *>(x + 44) = it.lead;
+    *reinterpret_cast<int32_t *>(x + 48) = it.delta;
+}
+
+__device__ __forceinline__ Item desc_get_item(const uint8_t *x)
+{
+    Item it;
+    it.g0 = sgpr64(*reinterpret_cast<const uint64_t *>(x + 16));
+    it.c_first = (int64_t)sgpr64((uint64_t)*reinterpret_cast<const int64_t *>(x + 24));
+    it.row = sgpr64(*reinterpret_cast<const uint64_t *>(x + 32));
+    it.cnt = sgpr32(*reinterpret_cast<const uint32_t *>(x + 40));
+    it.lead = sgpr32(*reinterpret_cast<const uint32_t *>(x + 44));
+    it.delta = (int32_t)sgpr32((uint32_t)*reinterpret_cast<const int32_t *>(x + 48));
+    it.rec = nullptr;
+    it.base = nullptr;
+    it.n_load = 0u;
     return it;
 }
 
@@ -122,15 +168,36 @@ __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p
     uint8_t *const chunk0 = a.out - p.head;
     // ---- 16 store steps over the staged bytes
     const int32_t bf = (int32_t)(it.c_first >> 4);                 // record byte of chunk 0's window (>= -1)
-    const int32_t delta = (int32_t)(it.rec - it.base);            // slab offset of record byte 0
+    const int32_t delta = it.delta;                                 // slab offset of record byte 0
     const uint32_t phase = (uint32_t)it.c_first & 15u;             // same for every chunk of the row
     // chunks 0 .. n_interior-1 lie wholly inside the row's GT text
     const int64_t room = (int64_t)gt_bytes - 16 - it.c_first;      // c_first + 16*i + 16 <= gt_bytes
     const uint32_t n_interior = room < 0 ? 0u : (uint32_t)min((int64_t)it.cnt, room / 16 + 1);
     const bool head_chunk = it.c_first < 0;                        // only (row 0, span 0) with an unaligned out
+    uint8_t *const span_ptr = chunk0 + (it.g0 - it.lead) * 16ull + lane * 16u;  // lane's chunk in step 0
+    const uint32_t first_plain = it.lead + (head_chunk ? 1u : 0u);               // steps at/after this position ...
+    const uint32_t end_plain = it.lead + n_interior;                              // ... and before this one are all-interior
+    const uint32_t pshift = ((phase >> 2) & 3u) * 2u;                             // bit offset of sample k0 in its byte (row-uniform)
+    const uint32_t psh = phase & 3u;                                              // byte phase of the text (row-uniform)
+    const int32_t slab_b0 = bf + delta - (int32_t)it.lead + (int32_t)lane;        // slab offset of the lane's window in step 0
 #pragma unroll 4
     for (uint32_t u = 0; u < kSpanChunks / 64u; u++) {
         if (u * 64u >= it.lead + it.cnt) break;
+        if (u * 64u >= first_plain && u * 64u + 64u <= end_plain) {
+            // every lane's chunk lies inside the row's text and inside the record: no clamps, no masks
+            uint16_t h;
+            __builtin_memcpy(&h, slab + slab_b0 + (int32_t)(u * 64u), 2);
+            const uint32_t w = (uint32_t)h >> pshift;
+            const uint32_t t0 = gt_text(w & 3u), t1 = gt_text((w >> 2) & 3u), t2 = gt_text((w >> 4) & 3u);
+            const uint32_t t3 = gt_text((w >> 6) & 3u), t4 = gt_text((w >> 8) & 3u);
+            u32x4 v;
+            v.x = funnel_bytes(t0, t1, psh);
+            v.y = funnel_bytes(t1, t2, psh);
+            v.z = funnel_bytes(t2, t3, psh);
+            v.w = funnel_bytes(t3, t4, psh);
+            store_chunk<NT>(span_ptr + u * 1024u, v);
+            continue;
+        }
         const uint32_t idx = u * 64u + lane;      // position inside the 1-KiB-aligned span
         const uint32_t i = idx - it.lead;         // chunk of this item (wraps to huge when idx < lead)
         if (i >= it.cnt) continue;
@@ -266,6 +333,7 @@ __global__ __launch_bounds__(kThreads) void gt_wide_kernel(EmitArgs a, WideParam
 // (LDS operations of one wave execute in order, and both waves live on one CU, so a flag written
 // after the slab's ds_writes is seen after them; compiler ordering is pinned with asm barriers).
 constexpr int kRingSlots = 3;
+constexpr int kDescSlots = kRingSlots + 1;  // slot s % 4 was last read in step s-4, whose `done` the loader saw in step s-1
 
 // Flag words are touched with explicit DS instructions: a volatile C++ access through a generic
 // pointer would become flat_load + s_waitcnt vmcnt(0), i.e. exactly the store drain this kernel
@@ -289,6 +357,7 @@ template <int NS, bool HAS_VIDX, bool NT>
 __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, WideParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][kRingSlots][kSlabBytes + kSlabExtra];
+    __shared__ __attribute__((aligned(16))) uint8_t s_desc[NS][kDescSlots][kDescBytes];
     __shared__ uint32_t s_full[NS][kRingSlots];
     __shared__ uint32_t s_done[NS][kRingSlots];
     const uint32_t lane = threadIdx.x & 63u;
@@ -308,18 +377,16 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, Wi
             const uint32_t slot = (uint32_t)(step % kRingSlots);
             v4u in0[NS], in1[NS];
             uint32_t nb[NS];
-            uint32_t n_load[NS];
             // issue every storer's loads for this step, then park them
 #pragma unroll
             for (int w = 0; w < NS; w++) {
                 const uint64_t t = step * items_per_step + (uint64_t)blockIdx.x * NS + w;
-                n_load[w] = 0u;
                 nb[w] = 0u;
                 in0[w] = v4u{0u, 0u, 0u, 0u};
                 in1[w] = v4u{0u, 0u, 0u, 0u};
                 if (t < p.n_items) {
                     const Item it = make_item<HAS_VIDX>(a, p, t);
-                    n_load[w] = it.n_load;
+                    if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], it, t);
                     if (lane < it.n_load) in0[w] = *reinterpret_cast<const v4u *>(it.base + lane * 16u);
                     if (lane + 64u < it.n_load) in1[w] = *reinterpret_cast<const v4u *>(it.base + (lane + 64u) * 16u);
                     // the chunk holding this row's '\n' needs the first record byte of row j+1
@@ -351,8 +418,8 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, Wi
             const uint64_t t = step * items_per_step + (uint64_t)blockIdx.x * NS + w;
             if (t >= p.n_items) break;
             const uint32_t slot = (uint32_t)(step % kRingSlots);
-            const Item it = make_item<HAS_VIDX>(a, p, t);
             while (lds_flag_read(lds_offset(&s_full[w][slot])) != (uint32_t)step + 1u) __builtin_amdgcn_s_sleep(1);
+            const Item it = desc_get_item(s_desc[w][step % kDescSlots]);
             emit_item<HAS_VIDX, NT, true>(a, p, it, slabs[w][slot], lane);
             // every ds_read of the slab has returned (its data fed the stores above): release the slot
             if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), (uint32_t)step + 1u);
@@ -374,6 +441,7 @@ template <int NS, bool HAS_VIDX, bool NT>
 __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a, WideParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][kRingSlots][kSlabBytes + kSlabExtra];
+    __shared__ __attribute__((aligned(16))) uint8_t s_desc[NS][kDescSlots][kDescBytes];
     __shared__ uint32_t s_full[NS][kRingSlots];
     __shared__ uint32_t s_done[NS][kRingSlots];
     const uint32_t lane = threadIdx.x & 63u;
@@ -398,7 +466,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                 const uint64_t hi = min(lo + per_range, p.n_items);
                 uint64_t got = 0;
                 if (lane == 0u) got = atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counters + range * 16u), (unsigned long long)NS);
-                got = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(got >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)got);
+                got = sgpr64(got);
                 if (lo + got < hi) {
                     t0 = lo + got;
                     break;
@@ -416,8 +484,12 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                 nb[w] = 0u;
                 in0[w] = v4u{0u, 0u, 0u, 0u};
                 in1[w] = v4u{0u, 0u, 0u, 0u};
+                // descriptor first (its ring has one slot more than the slab ring, so no wait is needed here)
+                const uint64_t t_tag = t0 == kNoItem ? kNoItem - 1ull : (t < t_end ? t : kNoItem);  // ~0-1 = "launch is out of work"
+                if (!(t0 != kNoItem && t < t_end) && lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], Item{}, t_tag);
                 if (t0 != kNoItem && t < t_end) {
                     const Item it = make_item<HAS_VIDX>(a, p, t);
+                    if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], it, t_tag);
                     if (lane < it.n_load) in0[w] = *reinterpret_cast<const v4u *>(it.base + lane * 16u);
                     if (lane + 64u < it.n_load) in1[w] = *reinterpret_cast<const v4u *>(it.base + (lane + 64u) * 16u);
                     const bool row_tail = it.cnt != 0u && it.c_first + 16ll * (int64_t)it.cnt >= (int64_t)p.row_bytes;
@@ -432,13 +504,9 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                     while (lds_flag_read(lds_offset(&s_done[w][slot])) != want) __builtin_amdgcn_s_sleep(1);
                 }
                 uint8_t *slab = slabs[w][slot];
-                const uint64_t t = (t0 != kNoItem && t0 + (uint64_t)w < t_end) ? t0 + (uint64_t)w : kNoItem;
                 *reinterpret_cast<v4u *>(slab + lane * 16u) = in0[w];
                 if (lane < 4u) *reinterpret_cast<v4u *>(slab + (lane + 64u) * 16u) = in1[w];
-                if (lane == 0u) {
-                    slab[kSlabBytes] = (uint8_t)nb[w];
-                    *reinterpret_cast<uint64_t *>(slab + kSlabBytes + 8u) = t0 == kNoItem ? kNoItem - 1ull : t;  // ~0-1 = "launch is out of work"
-                }
+                if (lane == 0u) slab[kSlabBytes] = (uint8_t)nb[w];
                 if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), (uint32_t)step + 1u);
             }
             if (t0 == kNoItem) break;
@@ -450,11 +518,12 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             const uint32_t slot = (uint32_t)(step % kRingSlots);
             while (lds_flag_read(lds_offset(&s_full[w][slot])) != (uint32_t)step + 1u) __builtin_amdgcn_s_sleep(1);
             const uint8_t *slab = slabs[w][slot];
-            uint64_t t = *reinterpret_cast<const uint64_t *>(slab + kSlabBytes + 8u);
-            t = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)t);
+            const uint8_t *desc = s_desc[w][step % kDescSlots];
+            uint64_t t = *reinterpret_cast<const uint64_t *>(desc + 8u);
+            t = sgpr64(t);
             if (t == kNoItem - 1ull) break;          // the loader found every range drained
             if (t != kNoItem) {                       // kNoItem: this storer has no item in this (last) step of a range
-                const Item it = make_item<HAS_VIDX>(a, p, t);
+                const Item it = desc_get_item(desc);
                 emit_item<HAS_VIDX, NT, true>(a, p, it, slab, lane);
             }
             if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), (uint32_t)step + 1u);

@@ -327,3 +327,21 @@ def test_config3_full_size_100k_by_500k():
             assert host.tobytes() == oracle.synth_records(n, 1, first_variant=j).tobytes()
         del out, recs
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("stream,dyn", [(7, 1), (7, 0), (3, 0), (0, 0)])
+def test_wide_kernel_many_steps_ring_reuse(monkeypatch, stream, dyn):
+    """Enough items per block that the loader/storer LDS ring is reused many times and the work queue
+    is drained and stolen from (few blocks, 20 000 rows), whole output compared with the oracle."""
+    monkeypatch.setenv("PGENHIP_WIDE_STREAM", str(stream))
+    monkeypatch.setenv("PGENHIP_WIDE_DYN", str(dyn))
+    monkeypatch.setenv("PGENHIP_WIDE_NT", "1")
+    monkeypatch.setenv("PGENHIP_WIDE_BLOCKS_PER_CU", "1")
+    n, v = 2504, 20_000
+    with pgen_rs_amd.GtEngine(n, device=0) as eng:
+        recs = eng.synth_records(v, first_variant=77)
+        out = eng.decode_emit(recs, v, kernel=_capi.KERNEL_WIDE)
+        eng.wait()
+        got = out.cpu().numpy()
+        host = recs.cpu().numpy()
+    assert got.tobytes() == oracle.decode_emit(host, v, n).tobytes()
