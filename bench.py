@@ -87,8 +87,8 @@ def cpu_baseline(sample_variants: int, n_samples: int, target_s: float = 12.0) -
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--variants", type=int, default=CHR22_VARIANTS, help="variants per GPU per step")
     ap.add_argument("--samples", type=int, default=CHR22_SAMPLES)
     ap.add_argument("--keep-modulus", type=int, default=0, help="keep sample i iff splitmix64(seed^i) %% m == 0 (0 = all)")

@@ -212,61 +212,63 @@ __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p
             const int32_t d = b0 - bb;
             window = d < 0 ? ((uint32_t)h << 8) & 0xFFFFu : (uint32_t)h >> (8u * (uint32_t)min(d, 2));
         }
-        if (i < n_interior && !(head_chunk && i == 0u)) {
-            store_chunk<NT>(dst, gt_text16_from_window(window, (int64_t)phase));
-            continue;
-        }
-        // ---- row tail: the chunk holds '\n' at byte nl (and the head of row j+1 behind it)
-        const int64_t c = it.c_first + 16ll * (int64_t)i;
-        const int64_t o = (int64_t)((it.g0 + i) * 16ull) - (int64_t)p.head;
-        const uint32_t nl = (uint32_t)((int64_t)gt_bytes - c);  // 0..15 when c >= 0
-        if (c >= 0 && (it.row + 1ull < a.n_variants || nl == 15u)) {
-            u32x4 x = gt_text16_from_window(window, c);
-            u32x4 y = {0u, 0u, 0u, 0u};
-            if (nl < 15u) {
-                const int64_t qy = -(int64_t)nl - 1;  // row j+1 starts nl+1 bytes into the chunk
-                // window of row j+1's first samples: record byte -1 (none) and byte 0
-                const uint32_t nb0 = NEXT_IN_SLAB ? (uint32_t)slab[kSlabBytes] : (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
-                y = gt_text16_from_window(nb0 << 8, qy);
-            }
-            uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-            uint32_t ys[4] = {y.x, y.y, y.z, y.w};
-            uint32_t os[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int32_t nb = (int32_t)nl - 4 * m;  // bytes of dword m taken from x
-                const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
-                uint32_t v = (xs[m] & mask) | (ys[m] & ~mask);
-                if (nb >= 0 && nb < 4) v = (v & ~(0xFFu << (8 * nb))) | (0x0Au << (8 * nb));
-                os[m] = v;
-            }
-            u32x4 v = {os[0], os[1], os[2], os[3]};
-            store_chunk<NT>(dst, v);
-        } else {
-            // first/last chunk of the whole stream: byte-wise with a validity mask
-            uint64_t rr = it.row;
-            int64_t cc = c;
-#pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const int64_t ob = o + b;
-                if (ob >= 0 && (uint64_t)ob < p.total_bytes) {
-                    if (cc >= (int64_t)S) {
-                        cc -= (int64_t)S;
-                        rr++;
-                    }
-                    uint32_t ch;
-                    if ((uint64_t)cc == gt_bytes) {
-                        ch = '\n';
-                    } else {
-                        const uint32_t s = (uint32_t)((uint64_t)cc >> 2);
-                        const uint32_t code = ((uint32_t)row_record<HAS_VIDX>(a, rr)[s >> 2] >> ((s & 3u) * 2u)) & 3u;
-                        ch = gt_text_byte(code, (uint32_t)cc & 3u);
-                    }
-                    dst[b] = (uint8_t)ch;
+        // interior lanes and the row-tail lane build their 16 bytes on different paths but leave through ONE
+        // store instruction (a second, one-lane store per row was 8 % of the kernel's store instructions)
+        u32x4 v = gt_text16_from_window(window, (int64_t)phase);
+        bool whole = i < n_interior && !(head_chunk && i == 0u);
+        if (!whole) {
+            // ---- row tail: the chunk holds '\n' at byte nl (and the head of row j+1 behind it)
+            const int64_t c = it.c_first + 16ll * (int64_t)i;
+            const int64_t o = (int64_t)((it.g0 + i) * 16ull) - (int64_t)p.head;
+            const uint32_t nl = (uint32_t)((int64_t)gt_bytes - c);  // 0..15 when c >= 0
+            if (c >= 0 && (it.row + 1ull < a.n_variants || nl == 15u)) {
+                u32x4 y = {0u, 0u, 0u, 0u};
+                if (nl < 15u) {
+                    const int64_t qy = -(int64_t)nl - 1;  // row j+1 starts nl+1 bytes into the chunk
+                    // window of row j+1's first samples: record byte -1 (none) and byte 0
+                    const uint32_t nb0 = NEXT_IN_SLAB ? (uint32_t)slab[kSlabBytes] : (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
+                    y = gt_text16_from_window(nb0 << 8, qy);
                 }
-                cc++;
+                uint32_t xs[4] = {v.x, v.y, v.z, v.w};  // v = row j's text from this chunk's first byte (c = phase mod 16)
+                uint32_t ys[4] = {y.x, y.y, y.z, y.w};
+                uint32_t os[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int32_t nb = (int32_t)nl - 4 * m;  // bytes of dword m taken from row j
+                    const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+                    uint32_t d = (xs[m] & mask) | (ys[m] & ~mask);
+                    if (nb >= 0 && nb < 4) d = (d & ~(0xFFu << (8 * nb))) | (0x0Au << (8 * nb));
+                    os[m] = d;
+                }
+                v = u32x4{os[0], os[1], os[2], os[3]};
+                whole = true;
+            } else {
+                // first/last chunk of the whole stream: byte-wise with a validity mask
+                uint64_t rr = it.row;
+                int64_t cc = c;
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    const int64_t ob = o + b;
+                    if (ob >= 0 && (uint64_t)ob < p.total_bytes) {
+                        if (cc >= (int64_t)S) {
+                            cc -= (int64_t)S;
+                            rr++;
+                        }
+                        uint32_t ch;
+                        if ((uint64_t)cc == gt_bytes) {
+                            ch = '\n';
+                        } else {
+                            const uint32_t s = (uint32_t)((uint64_t)cc >> 2);
+                            const uint32_t code = ((uint32_t)row_record<HAS_VIDX>(a, rr)[s >> 2] >> ((s & 3u) * 2u)) & 3u;
+                            ch = gt_text_byte(code, (uint32_t)cc & 3u);
+                        }
+                        dst[b] = (uint8_t)ch;
+                    }
+                    cc++;
+                }
             }
         }
+        if (whole) store_chunk<NT>(dst, v);
     }
 }
 
