@@ -249,23 +249,14 @@ hipError_t launch_gt_flat(const EmitArgs &a, int num_cus, hipStream_t stream)
           gt_flat_kernel<U_, NT_, L16_, WC_, true, 2>}},                                                \
             U_                                                                                          \
     }
+    // the round-1 sweep (profiles/r01_kernel_sweeps.md) covered 13 builds; three are kept compiled:
     static const Variant table[] = {
-        PGENHIP_FLAT_VARIANT(4, false, false, false),  // 0
-        PGENHIP_FLAT_VARIANT(4, true, false, false),   // 1 nt
-        PGENHIP_FLAT_VARIANT(4, false, true, false),   // 2 load16
-        PGENHIP_FLAT_VARIANT(4, false, false, true),   // 3 wave-contig
-        PGENHIP_FLAT_VARIANT(8, false, false, false),  // 4 U=8
-        PGENHIP_FLAT_VARIANT(8, true, true, true),     // 5 all
-        PGENHIP_FLAT_VARIANT(2, false, false, false),  // 6 U=2
-        PGENHIP_FLAT_VARIANT(4, true, true, false),    // 7 nt+load16
-        PGENHIP_FLAT_VARIANT(8, true, false, false),   // 8 U=8 nt
-        PGENHIP_FLAT_VARIANT(4, true, false, true),    // 9 U=4 nt wave-contig
-        PGENHIP_FLAT_VARIANT(8, true, true, false),    // 10 U=8 nt load16
-        PGENHIP_FLAT_VARIANT(2, true, true, false),    // 11 U=2 nt load16
-        PGENHIP_FLAT_VARIANT(16, true, true, true),    // 12 U=16 all
+        PGENHIP_FLAT_VARIANT(4, false, false, false),  // 0 plain stores
+        PGENHIP_FLAT_VARIANT(4, true, false, false),   // 1 nontemporal stores (default)
+        PGENHIP_FLAT_VARIANT(8, true, true, true),     // 2 U=8, nontemporal, 16-bit window loads, wave-contiguous
     };
 #undef PGENHIP_FLAT_VARIANT
-    const Variant &vr = table[(variant >= 0 && variant < (int)(sizeof(table) / sizeof(table[0]))) ? variant : 0];
+    const Variant &vr = table[(variant >= 0 && variant < (int)(sizeof(table) / sizeof(table[0]))) ? variant : 1];
     const uint32_t tile_chunks = kThreads * vr.u;
     const uint32_t tile_bytes = tile_chunks * 16u;
     p.n_tiles = (p.n_chunks + tile_chunks - 1ull) / tile_chunks;
