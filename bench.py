@@ -64,13 +64,52 @@ def cpu_baseline(sample_variants: int, n_samples: int, target_s: float = 12.0) -
                 raise RuntimeError(f"oracle baseline failed: {rc}")
         out_bytes = out.stat().st_size
         assert out_bytes == sample_variants * (4 * n_samples + 1)
-    finally:
+    except BaseException:
         for p in (pgen, out):
             try:
                 p.unlink()
             except FileNotFoundError:
                 pass
+        raise
+    out.unlink()
+    # the same loop on all host cores (variant ranges -> separate files): NOT the reference's behaviour
+    # (pgen-rs is single-threaded), reported beside it as BASELINE.md asks
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    all_cores = None
+    try:
+        bounds = [sample_variants * i // cores for i in range(cores + 1)]
+        idx = [np.arange(bounds[i], bounds[i + 1], dtype=np.uint32) for i in range(cores)]
+        outs = [shm / f"pgenhip_bench_{os.getpid()}_{i}.vcfbody" for i in range(cores)]
+
+        def one(i):  # ctypes releases the GIL for the duration of the C call
+            return oracle.output_vcf_body_file(str(pgen), n_samples, str(outs[i]), var_idx=idx[i])
+
+        reps, t_all = 0, 0.0
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            while t_all < target_s / 3 and reps < 64:
+                t0 = time.perf_counter()
+                rcs = list(ex.map(one, range(cores)))
+                t_all += time.perf_counter() - t0
+                reps += 1
+                if any(rcs):
+                    raise RuntimeError(f"oracle baseline failed: {rcs}")
+        all_cores = {"value": reps * sample_variants * n_samples / t_all, "unit": "genotypes/s", "cores": cores,
+                     "seconds": t_all, "note": "same C loop, variant ranges on all host cores, one output file per thread; not the reference's behaviour"}
+    finally:
+        for o in list(locals().get("outs", [])):
+            try:
+                o.unlink()
+            except FileNotFoundError:
+                pass
+    try:
+        pgen.unlink()
+    except FileNotFoundError:
+        pass
     return {
+        "all_cores": all_cores,
         "value": passes * sample_variants * n_samples / dt,
         "unit": "genotypes/s",
         "cores": 1,
