@@ -89,7 +89,8 @@ uint64_t pgenhip_gt_row_bytes(const pgenhip_ctx *ctx);
 #define PGENHIP_KERNEL_ROWS 1u   /* general row-tiled kernel (any stride/alignment, list gather) */
 #define PGENHIP_KERNEL_FLAT 2u   /* dense all-samples stream kernel (out_stride == 4N+1) */
 #define PGENHIP_KERNEL_SCAN 3u   /* kept-subset scan + wave ballot/popcount compaction */
-#define PGENHIP_KERNEL_WIDE 4u   /* dense all-samples, wide LDS-staged record loads (N >= 1024) */
+#define PGENHIP_KERNEL_WIDE 4u   /* dense all-samples, wide LDS-staged record loads, one row piece per item (N >= 1024) */
+#define PGENHIP_KERNEL_SPAN 5u   /* dense all-samples, 16-KiB stream spans across row ends (N >= 2048) */
 #define PGENHIP_KERNEL_MASK 0xFu
 
 /* src/pfile.rs:165-190 for a block of n_variants kept variants.

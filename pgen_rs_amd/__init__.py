@@ -10,6 +10,7 @@ from ._capi import (  # noqa: F401
     KERNEL_FLAT,
     KERNEL_ROWS,
     KERNEL_SCAN,
+    KERNEL_SPAN,
     KERNEL_WIDE,
     PgenHipError,
 )
@@ -33,4 +34,5 @@ __all__ = [
     "KERNEL_FLAT",
     "KERNEL_SCAN",
     "KERNEL_WIDE",
+    "KERNEL_SPAN",
 ]

@@ -35,6 +35,7 @@ KERNEL_ROWS = 1
 KERNEL_FLAT = 2
 KERNEL_SCAN = 3
 KERNEL_WIDE = 4
+KERNEL_SPAN = 5
 SYNTH_DIRTY_PAD = 1
 
 u8p = C.POINTER(C.c_uint8)

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <new>
 #include <string>
 #include <vector>
@@ -283,7 +285,12 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
                     ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank};
                     HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
                 }
-            } else if (gt_wide_applicable(a))
+            } else if (gt_span_applicable(a) && getenv("PGENHIP_USE_SPAN"))
+                // stream-span kernel: 10 % fewer store instructions than the row-item kernel but more scalar work;
+                // interleaved A/B puts the two within 1-2 % (profiles/r01_kernel_sweeps.md, probe9), so the simpler
+                // row-item kernel stays the default and this one is opt-in
+                HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream));
+            else if (gt_wide_applicable(a))
                 HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
             else if (gt_flat_applicable(a))
                 HIP_TRY(launch_gt_flat(a, ctx->num_cus, ctx->stream));
@@ -300,6 +307,10 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
             HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         }
+        case PGENHIP_KERNEL_SPAN:
+            if (!gt_span_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "span kernel needs all samples kept, N >= 2048 and out_stride == 4N+1");
+            HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
         case PGENHIP_KERNEL_WIDE:
             if (!gt_wide_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "wide kernel needs all samples kept, N >= 1024 and out_stride == 4N+1");
             HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));

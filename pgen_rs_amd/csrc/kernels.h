@@ -38,6 +38,11 @@ hipError_t launch_gt_flat(const EmitArgs &a, int num_cus, hipStream_t stream);
 bool gt_wide_applicable(const EmitArgs &a);
 hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream);
 
+// Stream-span kernel: like the wide stream kernel, but a work item is a 1-KiB-aligned 16-KiB span of the
+// output stream (crossing row ends), so every store step is a full 1 KiB (N >= 2048; needs work_counters).
+bool gt_span_applicable(const EmitArgs &a);
+hipError_t launch_gt_span(const EmitArgs &a, int num_cus, hipStream_t stream);
+
 // Kept-subset scan kernel: per-context keep bitmap (N bits, zero-padded to whole segments of
 // kScanSegmentSamples) + number of kept samples before each segment.
 constexpr uint32_t kScanSegmentSamples = 16384u;

@@ -28,6 +28,8 @@ def kernels_for(subset: bool, dense: bool, n: int = 0):
         ks.append(_capi.KERNEL_FLAT)
     if not subset and dense and n >= 1024:
         ks.append(_capi.KERNEL_WIDE)
+    if not subset and dense and n >= 2048:
+        ks.append(_capi.KERNEL_SPAN)
     if subset and n >= 61:  # the scan kernel needs records of >= 16 bytes
         ks.append(_capi.KERNEL_SCAN)
     return ks
@@ -85,7 +87,7 @@ def test_golden_sha_with_device_synth(name):
             assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == spec["gt_sha256"], f"kernel {kern}"
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 66, 67, 255, 256, 257, 511, 513, 1023, 1024, 1025, 2504, 4093, 4095, 4096, 4097, 4099, 16385, 70001])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 66, 67, 255, 256, 257, 511, 513, 1023, 1024, 1025, 2047, 2048, 2049, 2051, 2504, 4093, 4095, 4096, 4097, 4099, 8191, 8193, 16385, 70001])
 def test_all_samples_vs_oracle(n):
     rng = np.random.default_rng(n + 1)
     v = 11
@@ -102,7 +104,7 @@ def test_all_samples_vs_oracle(n):
 @pytest.mark.parametrize("out_offset", range(0, 17))
 def test_unaligned_output_pointer(out_offset):
     rng = np.random.default_rng(100 + out_offset)
-    n, v = (131, 6) if out_offset % 2 else (1031, 5)
+    n, v = ((131, 6) if out_offset % 2 else (1031, 5)) if out_offset % 3 else (2053, 9)
     r = oracle.variant_record_size(n)
     recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
     want = oracle.decode_emit(recs, v, n).reshape(v, -1)
@@ -345,3 +347,25 @@ def test_wide_kernel_many_steps_ring_reuse(monkeypatch, stream, dyn):
         got = out.cpu().numpy()
         host = recs.cpu().numpy()
     assert got.tobytes() == oracle.decode_emit(host, v, n).tobytes()
+
+
+@pytest.mark.parametrize("nt", [0, 1])
+def test_span_kernel_many_steps_and_shapes(monkeypatch, nt):
+    """The stream-span kernel: many steps per block (ring reuse, work-queue stealing), rows of 1, 2 and many
+    spans, unaligned output pointers, variant gather — whole outputs against the oracle."""
+    monkeypatch.setenv("PGENHIP_WIDE_NT", str(nt))
+    monkeypatch.setenv("PGENHIP_WIDE_BLOCKS_PER_CU", "1")
+    rng = np.random.default_rng(900 + nt)
+    for n, v, off in [(2504, 20_000, 0), (2048, 3_001, 7), (2049, 777, 16), (4095, 501, 127), (4100, 300, 3), (8190, 211, 0), (40_001, 57, 5), (70_001, 9, 0)]:
+        r = oracle.variant_record_size(n)
+        recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
+        want = oracle.decode_emit(recs, v, n).reshape(v, -1)
+        got, _ = run_engine(recs, v, n, kernel=_capi.KERNEL_SPAN, out_offset=off)
+        exp = expect_buffer(want, v, n, 4 * n + 1, off, got.size)
+        assert (got == exp).all(), f"n={n} v={v} off={off}"
+    vidx = [5, 0, 3, 3, 9, 1]
+    n = 3000
+    recs = rng.integers(0, 256, size=10 * oracle.variant_record_size(n), dtype=np.uint8)
+    want = oracle.decode_emit(recs, len(vidx), n, variant_idx=vidx).reshape(len(vidx), -1)
+    got, _ = run_engine(recs, len(vidx), n, kernel=_capi.KERNEL_SPAN, variant_idx=vidx)
+    assert (got == expect_buffer(want, len(vidx), n, 4 * n + 1, 0, got.size)).all()
