@@ -15,12 +15,18 @@ namespace pgenhip {
 // Bytes 0 and 2 are constant; byte 1 is "001."[code], byte 3 is "011."[code].
 // v_perm_b32 picks both from two 4-byte tables with one selector (selector values 0-3 = bytes of
 // the second operand, 4-7 = bytes of the first, 0x0C = constant 0x00), so a genotype costs
-// v_mad_u32_u24 + v_perm_b32 + v_or_b32.
+// v_mul_u32_u24 + v_lshl_or_b32 + v_perm_b32 + v_or_b32.
 __device__ __forceinline__ uint32_t gt_text(uint32_t code)
 {
     constexpr uint32_t kTabA = 0x2E313030u;  // '0','0','1','.'  (allele 1 char by code)
     constexpr uint32_t kTabB = 0x2E313130u;  // '0','1','1','.'  (allele 2 char by code)
-    uint32_t sel = 0x000C040Cu + code * 0x01000100u;
+    // selector = 0x000C040C | code << 8 | code << 24.  Written as a 24-bit multiply + shift-or: a plain
+    // `code * 0x01000100` compiles to v_mul_lo_u32 (quarter rate) + v_add, and these kernels are issue-bound.
+    // The multiply is pinned with inline asm: hipcc folds `(umul24(code, 0x010001) << 8)` straight back into
+    // v_mul_lo_u32 by 0x01000100.
+    uint32_t spread;  // code | code << 16
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(spread) : "v"(code), "v"(0x010001u));
+    const uint32_t sel = (spread << 8) | 0x000C040Cu;  // v_lshl_or_b32
     return __builtin_amdgcn_perm(kTabA, kTabB, sel) | 0x002F0009u;
 }
 

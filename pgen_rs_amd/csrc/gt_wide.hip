@@ -460,21 +460,29 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
         const uint64_t per_range = (p.n_items + 7ull) / 8ull;
         uint32_t range = blockIdx.x & 7u;
         uint32_t drained = 0u;  // consecutive ranges found empty
+        // The claim for step s+1 is ISSUED right after step s's record loads and only read at the top of step
+        // s+1, so the atomic's round trip (1-2 us under load) hides behind the load latency instead of adding
+        // to every step of this wave — the storers wait for nothing else.
+        auto issue_claim = [&](uint32_t rng) -> uint64_t {
+            uint64_t got = 0;
+            if (lane == 0u) got = atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counters + rng * 16u), (unsigned long long)NS);
+            return got;
+        };
+        uint64_t pending = issue_claim(range);
         for (uint64_t step = 0;; step++) {
-            // ---- claim NS consecutive items (lane 0 asks, the wave shares the answer)
+            // ---- resolve the claim issued one step ago (lane 0 asked, the wave shares the answer)
             uint64_t t0 = kNoItem;
+            uint64_t got = sgpr64(pending);
             while (drained < 8u) {
                 const uint64_t lo = (uint64_t)range * per_range;
                 const uint64_t hi = min(lo + per_range, p.n_items);
-                uint64_t got = 0;
-                if (lane == 0u) got = atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counters + range * 16u), (unsigned long long)NS);
-                got = sgpr64(got);
                 if (lo + got < hi) {
                     t0 = lo + got;
                     break;
                 }
                 range = (range + 1u) & 7u;  // own range drained: steal from the next one
                 drained++;
+                if (drained < 8u) got = sgpr64(issue_claim(range));
             }
             const uint64_t t_end = t0 == kNoItem ? 0ull : min(t0 + NS, min(((uint64_t)range + 1ull) * per_range, p.n_items));
             const uint32_t slot = (uint32_t)(step % kRingSlots);
@@ -499,6 +507,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                         nb[w] = (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
                 }
             }
+            if (t0 != kNoItem) pending = issue_claim(range);  // for the next step; read at the top of the loop
 #pragma unroll
             for (int w = 0; w < NS; w++) {
                 if (step >= (uint64_t)kRingSlots) {
