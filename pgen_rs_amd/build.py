@@ -32,6 +32,10 @@ HIPCC_FLAGS = [
     "-Wextra",
     "-Wno-unused-parameter",
     "-fno-gpu-rdc",
+    # the work-queue claims are single-lane returning atomics whose result is consumed a whole step later;
+    # the wave-reduction rewrite of the atomic optimizer would read the result back at once (s_waitcnt vmcnt(0))
+    "-mllvm",
+    "-amdgpu-atomic-optimizer-strategy=None",
 ]
 
 

@@ -80,39 +80,55 @@ struct Item {
     uint32_t n_load;      // 16-byte pieces to stage (<= 66)
     int32_t delta;        // slab offset of record byte 0 (= rec - base)
     uint64_t row;         // j
+    bool row_tail;        // the item holds the row's last chunk (the one with its '\n')
 };
 
+// Item (row j, span k).  Only the row's place in the stream needs 64-bit arithmetic; everything
+// else is computed RELATIVE to the row's first chunk in 32 bits (a row has at most 2^30 + 1 chunks),
+// because gfx9's scalar unit has no 64-bit ordered compare — every 64-bit min/max becomes a VALU
+// compare plus a round trip through VCC, and the loader wave computes seven items per step.
 template <bool HAS_VIDX>
-__device__ __forceinline__ Item make_item(const EmitArgs &a, const WideParams &p, uint64_t t)
+__device__ __forceinline__ Item make_item_at(const EmitArgs &a, const WideParams &p, uint64_t j, uint32_t k)
 {
     Item it;
     const uint64_t S = p.row_bytes;
-    const uint64_t j = p.spans_per_row == 1u ? t : t / p.spans_per_row;
-    const uint32_t k = p.spans_per_row == 1u ? 0u : (uint32_t)(t - j * p.spans_per_row);
     const uint64_t row_start = j * S;
     // row j owns the chunks whose first byte lies in [j*S, (j+1)*S); row 0 also the chunk that
     // holds stream byte 0.  Spans are cut on 64-chunk (1 KiB) boundaries of the chunk grid so every
     // store instruction of a wave covers eight WHOLE 128-B lines (except at the two row ends).
     const uint64_t g_first = j == 0 ? (uint64_t)(p.head >> 4) : (row_start + p.head + 15ull) >> 4;
     const uint64_t g_end = (row_start + S + p.head + 15ull) >> 4;
-    const uint64_t span_base = (g_first & ~63ull) + (uint64_t)k * kSpanChunks;
-    const uint64_t span_end = min(g_end, span_base + kSpanChunks);
+    const int32_t row_chunks = (int32_t)(uint32_t)(g_end - g_first);
+    const int32_t base_rel = (int32_t)(k * kSpanChunks) - (int32_t)((uint32_t)g_first & 63u);  // span base - g_first
+    const int32_t end_rel = min(row_chunks, base_rel + (int32_t)kSpanChunks);
+    const int32_t g0_rel = max(base_rel, 0);
+    // row-relative byte offset of chunk g_first: 0..15 (row 0: -(head & 15)); exact modulo 2^32
+    const int32_t row_c_first = (int32_t)((uint32_t)g_first * 16u - p.head - (uint32_t)row_start);
     it.row = j;
-    it.g0 = max(g_first, span_base);
-    it.cnt = it.g0 < span_end ? (uint32_t)(span_end - it.g0) : 0u;
-    it.lead = (uint32_t)(it.g0 - span_base);
-    it.c_first = (int64_t)(it.g0 * 16ull) - (int64_t)p.head - (int64_t)row_start;
+    it.g0 = g_first + (uint64_t)(uint32_t)g0_rel;
+    it.cnt = end_rel > g0_rel ? (uint32_t)(end_rel - g0_rel) : 0u;
+    it.lead = (uint32_t)(g0_rel - base_rel);
+    it.row_tail = it.cnt != 0u && end_rel == row_chunks;  // <=> c_first + 16 cnt >= S
+    it.c_first = (int64_t)row_c_first + ((int64_t)g0_rel << 4);
     it.rec = row_record<HAS_VIDX>(a, j);
-    const uint32_t last = a.record_size - 1u;
-    const int64_t bf = it.c_first >> 4;  // first record byte needed (-1 for the head chunk)
-    const uint32_t b_first = bf > 0 ? (uint32_t)min(bf, (int64_t)last - 1) : 0u;  // R >= 2
-    const uint32_t b_last = (uint32_t)min(bf + (int64_t)it.cnt, (int64_t)last);  // window hi byte of the last chunk
+    const int32_t last = (int32_t)(a.record_size - 1u);
+    const int32_t bf = g0_rel + (row_c_first >> 4);  // = c_first >> 4: first record byte needed (-1 for the head chunk)
+    const uint32_t b_first = bf > 0 ? (uint32_t)min(bf, last - 1) : 0u;  // R >= 2
+    const uint32_t b_last = (uint32_t)min(bf + (int32_t)it.cnt, last);  // window hi byte of the last chunk
     const uint64_t addr_first = (uint64_t)(uintptr_t)(it.rec + b_first);
     const uint32_t mis = (uint32_t)(addr_first & 15ull);
     it.base = it.rec + b_first - mis;
     it.n_load = it.cnt ? (mis + (b_last - b_first)) / 16u + 1u : 0u;
     it.delta = (int32_t)mis - (int32_t)b_first;
     return it;
+}
+
+template <bool HAS_VIDX>
+__device__ __forceinline__ Item make_item(const EmitArgs &a, const WideParams &p, uint64_t t)
+{
+    const uint64_t j = p.spans_per_row == 1u ? t : t / p.spans_per_row;
+    const uint32_t k = p.spans_per_row == 1u ? 0u : (uint32_t)(t - j * p.spans_per_row);
+    return make_item_at<HAS_VIDX>(a, p, j, k);
 }
 
 
@@ -149,6 +165,7 @@ __device__ __forceinline__ Item desc_get_item(const uint8_t *x)
     it.delta = (int32_t)sgpr32((uint32_t)*reinterpret_cast<const int32_t *>(x + 48));
     it.rec = nullptr;
     it.base = nullptr;
+    it.row_tail = false;
     it.n_load = 0u;
     return it;
 }
@@ -469,7 +486,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             return got;
         };
         uint64_t pending = issue_claim(range);
-        for (uint64_t step = 0;; step++) {
+        for (uint32_t step = 0;; step++) {
             // ---- resolve the claim issued one step ago (lane 0 asked, the wave shares the answer)
             uint64_t t0 = kNoItem;
             uint64_t got = sgpr64(pending);
@@ -488,46 +505,58 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             const uint32_t slot = (uint32_t)(step % kRingSlots);
             v4u in0[NS], in1[NS];
             uint32_t nb[NS];
+            // one division per step: the step's items are consecutive, so (row, span) just counts on
+            uint64_t j_it = 0ull;
+            uint32_t k_it = 0u;
+            if (t0 != kNoItem) {
+                j_it = p.spans_per_row == 1u ? t0 : t0 / p.spans_per_row;
+                k_it = p.spans_per_row == 1u ? 0u : (uint32_t)(t0 - j_it * p.spans_per_row);
+            }
+            const uint32_t n_here = t0 == kNoItem ? 0u : (uint32_t)(t_end - t0);  // items of this step (<= NS)
 #pragma unroll
             for (int w = 0; w < NS; w++) {
-                const uint64_t t = t0 == kNoItem ? kNoItem : t0 + (uint64_t)w;
                 nb[w] = 0u;
                 in0[w] = v4u{0u, 0u, 0u, 0u};
                 in1[w] = v4u{0u, 0u, 0u, 0u};
                 // descriptor first (its ring has one slot more than the slab ring, so no wait is needed here)
-                const uint64_t t_tag = t0 == kNoItem ? kNoItem - 1ull : (t < t_end ? t : kNoItem);  // ~0-1 = "launch is out of work"
-                if (!(t0 != kNoItem && t < t_end) && lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], Item{}, t_tag);
-                if (t0 != kNoItem && t < t_end) {
-                    const Item it = make_item<HAS_VIDX>(a, p, t);
-                    if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], it, t_tag);
+                if ((uint32_t)w >= n_here) {
+                    // ~0-1 = "launch is out of work", ~0 = no item for this storer in this (last) step of a range
+                    if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], Item{}, t0 == kNoItem ? kNoItem - 1ull : kNoItem);
+                } else {
+                    const Item it = make_item_at<HAS_VIDX>(a, p, j_it, k_it);
+                    if (++k_it == p.spans_per_row) {
+                        k_it = 0u;
+                        j_it++;
+                    }
+                    if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], it, t0 + (uint64_t)w);
                     if (lane < it.n_load) in0[w] = *reinterpret_cast<const v4u *>(it.base + lane * 16u);
                     if (lane + 64u < it.n_load) in1[w] = *reinterpret_cast<const v4u *>(it.base + (lane + 64u) * 16u);
-                    const bool row_tail = it.cnt != 0u && it.c_first + 16ll * (int64_t)it.cnt >= (int64_t)p.row_bytes;
-                    if (row_tail && it.row + 1ull < a.n_variants && lane == 0u)
+                    // rows < n_variants <= 2^32 - 1, so row + 1 fits 32 bits
+                    if (it.row_tail && (uint32_t)it.row + 1u < a.n_variants && lane == 0u)
                         nb[w] = (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
                 }
             }
             if (t0 != kNoItem) pending = issue_claim(range);  // for the next step; read at the top of the loop
 #pragma unroll
             for (int w = 0; w < NS; w++) {
-                if (step >= (uint64_t)kRingSlots) {
-                    const uint32_t want = (uint32_t)(step - kRingSlots) + 1u;
+                if (step >= kRingSlots) {
+                    const uint32_t want = step - kRingSlots + 1u;
                     while (lds_flag_read(lds_offset(&s_done[w][slot])) != want) __builtin_amdgcn_s_sleep(1);
                 }
                 uint8_t *slab = slabs[w][slot];
                 *reinterpret_cast<v4u *>(slab + lane * 16u) = in0[w];
                 if (lane < 4u) *reinterpret_cast<v4u *>(slab + (lane + 64u) * 16u) = in1[w];
                 if (lane == 0u) slab[kSlabBytes] = (uint8_t)nb[w];
-                if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), (uint32_t)step + 1u);
+                if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), step + 1u);
             }
             if (t0 == kNoItem) break;
         }
     } else {
         // ------------------------------ storer waves -----------------------------
         const uint32_t w = wave - 1u;
-        for (uint64_t step = 0;; step++) {
-            const uint32_t slot = (uint32_t)(step % kRingSlots);
-            while (lds_flag_read(lds_offset(&s_full[w][slot])) != (uint32_t)step + 1u) __builtin_amdgcn_s_sleep(1);
+        for (uint32_t step = 0;; step++) {  // 32-bit: a block that ran 2^32 steps would have written > 2^47 bytes
+            const uint32_t slot = step % kRingSlots;
+            while (lds_flag_read(lds_offset(&s_full[w][slot])) != step + 1u) __builtin_amdgcn_s_sleep(1);
             const uint8_t *slab = slabs[w][slot];
             const uint8_t *desc = s_desc[w][step % kDescSlots];
             uint64_t t = *reinterpret_cast<const uint64_t *>(desc + 8u);
@@ -537,7 +566,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                 const Item it = desc_get_item(desc);
                 emit_item<HAS_VIDX, NT, true>(a, p, it, slab, lane);
             }
-            if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), (uint32_t)step + 1u);
+            if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), step + 1u);
         }
     }
 }
