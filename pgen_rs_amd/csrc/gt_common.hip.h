@@ -99,4 +99,25 @@ __device__ __forceinline__ u32x4 gt_text16_from_window(uint32_t window, int64_t 
     return v;
 }
 
+// ---- LDS flag words for wave-to-wave hand-over inside a block -----------------------------------
+// Flag words are touched with explicit DS instructions: a volatile C++ access through a generic
+// pointer would become flat_load + s_waitcnt vmcnt(0), i.e. exactly the store drain the role-split
+// kernels exist to avoid.  The low 32 bits of a generic pointer into LDS are the LDS byte offset.
+// (LDS operations of one wave execute in order and both waves live on one CU, so a flag written
+// after a wave's data ds_writes is seen after them; compiler ordering is pinned by the asm barriers.)
+__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)(uintptr_t)p; }
+
+__device__ __forceinline__ uint32_t lds_flag_read(uint32_t off)
+{
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ void lds_flag_write(uint32_t off, uint32_t value)
+{
+    // everything this wave sent to the LDS before (data writes / data reads) has completed first
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(off), "v"(value) : "memory");
+}
+
 }  // namespace pgenhip

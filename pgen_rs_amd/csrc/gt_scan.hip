@@ -38,30 +38,128 @@ constexpr uint32_t kFlushCodes = 2048;                  // pending codes that tr
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
+template <uint32_t RING = kRing>
 __device__ __forceinline__ uint32_t ring_code(const uint8_t *ring, uint32_t rel)
 {
-    return ring[rel & (kRing - 1u)];
+    return ring[rel & (RING - 1u)];
 }
 
-// DENSE: most samples are kept (host decides from K/N): compact one record byte (4 samples) per step
-// instead of one kept sample per step.  A separate instantiation keeps the sparse build's registers low.
-template <bool HAS_VIDX, bool DENSE>
-__global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups)
+// Compaction of one lane's 64 samples of a tile: kept codes go to the ring at their rank
+// (src/pfile.rs:171-175).  `pos` = rank of the lane's first kept sample relative to the segment
+// start, `ring_base` = ring position of the row's rank 0.
+// DENSE: most samples are kept (host decides from K/N): one record byte (4 samples) per step
+// instead of one kept sample per step; a fully kept byte becomes one 4-byte ring write.
+template <bool DENSE>
+__device__ __forceinline__ void compact_lane(uint8_t *ring, uint32_t ring_base, uint64_t lo, uint64_t hi, uint64_t mm, uint32_t pos)
 {
-    __shared__ uint64_t s_mask[kSegWords];
-    __shared__ uint32_t s_pre[kSegWords + 1];
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kWaves][kRing];
+    pos += ring_base;
+    if (DENSE) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t nib = (uint32_t)(mm >> (4 * q)) & 0xFu;
+            if (nib == 0u) continue;
+            const uint32_t x = (uint32_t)((q < 8 ? lo : hi) >> (8 * (q & 7))) & 0xFFu;
+            if (nib == 0xFu) {
+                const uint32_t d = (x & 3u) | ((x & 0xCu) << 6) | ((x & 0x30u) << 12) | ((x & 0xC0u) << 18);
+                const uint32_t idx = pos & (kRing - 1u);
+                if (idx <= kRing - 4u) {
+                    __builtin_memcpy(ring + idx, &d, 4);
+                } else {
+                    ring[idx] = (uint8_t)d;
+                    ring[(idx + 1u) & (kRing - 1u)] = (uint8_t)(d >> 8);
+                    ring[(idx + 2u) & (kRing - 1u)] = (uint8_t)(d >> 16);
+                    ring[(idx + 3u) & (kRing - 1u)] = (uint8_t)(d >> 24);
+                }
+                pos += 4u;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (nib & (1u << e)) {
+                        ring[pos & (kRing - 1u)] = (uint8_t)((x >> (2 * e)) & 3u);
+                        pos++;
+                    }
+                }
+            }
+        }
+    } else {
+        while (mm != 0ull) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            const uint64_t half = bit < 32u ? lo : hi;
+            ring[pos & (kRing - 1u)] = (uint8_t)((half >> ((bit & 31u) * 2u)) & 3ull);
+            pos++;
+        }
+    }
+}
 
-    const uint32_t tid = threadIdx.x;
+// A lane's 16 record bytes as two 64-bit halves; a window that was pulled back by `tail_shift`
+// bytes at the record tail is shifted into place.
+__device__ __forceinline__ void window_halves(const v4u &w, uint32_t tail_shift, uint64_t &lo, uint64_t &hi)
+{
+    lo = (uint64_t)w.x | ((uint64_t)w.y << 32);
+    hi = (uint64_t)w.z | ((uint64_t)w.w << 32);
+    if (tail_shift != 0u) {
+        const uint32_t sh8 = tail_shift * 8u;
+        if (sh8 >= 128u) { lo = 0ull; hi = 0ull; }
+        else if (sh8 >= 64u) { lo = hi >> (sh8 - 64u); hi = 0ull; }
+        else { lo = (lo >> sh8) | (hi << (64u - sh8)); hi >>= sh8; }
+    }
+}
+
+// Output-driven flush of row bytes [emitted, hi_emit) of one row.  Whole 16-byte-ALIGNED chunks:
+// one lane per chunk reads five consecutive kept codes from the ring (rank r of the segment sits
+// at ring position ring_base + r), expands them to text (src/pfile.rs:177-190), funnel-shifts by
+// the row's phase and stores 16 B.  The up to 15 bytes before the first and after the last whole
+// chunk (segment / row edges, shared with the neighbouring segment's block) go out as ONE
+// byte-store instruction: lanes 0-15 take the head bytes, lanes 16-31 the tail bytes.
+// All 64-bit arithmetic is wave-uniform (scalar unit); a lane only adds a 32-bit offset.
+template <uint32_t RING = kRing>
+__device__ __forceinline__ void flush_range(const uint8_t *ring, uint32_t ring_base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
+                                            uint32_t seg_k0, uint32_t K, uint32_t lane)
+{
+    uint8_t *const out0 = row_out + emitted;                           // first byte of the flush
+    const uint32_t len = (uint32_t)(hi_emit - emitted);                // <= 4 * 16 384 + 1
+    const uint32_t mis = (uint32_t)(uintptr_t)out0 & 15u;
+    const uint32_t head = min((16u - mis) & 15u, len);                 // bytes before the first whole chunk
+    const uint32_t n_chunks = (len - head) >> 4;
+    const uint32_t tail_off = head + (n_chunks << 4);
+    const uint32_t tail = len - tail_off;                              // bytes after the last whole chunk (< 16)
+    const uint32_t e4 = ring_base + (uint32_t)(emitted >> 2) - seg_k0; // ring position of the code under byte `emitted`
+    const uint32_t em = (uint32_t)emitted & 3u;
+    const uint64_t nl64 = 4ull * K - emitted;                          // flush offset of the row's '\n' (row byte 4K)
+    const uint32_t nl = nl64 < (uint64_t)len ? (uint32_t)nl64 : 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < n_chunks; i += 64u) {
+        const uint32_t off = head + (i << 4);
+        const uint32_t x = em + off;                                   // byte offset from the dword boundary under `emitted`
+        const uint32_t rel = e4 + (x >> 2);
+        const uint32_t sh = x & 3u;
+        const uint32_t t0 = gt_text(ring_code<RING>(ring, rel));
+        const uint32_t t1 = gt_text(ring_code<RING>(ring, rel + 1u));
+        const uint32_t t2 = gt_text(ring_code<RING>(ring, rel + 2u));
+        const uint32_t t3 = gt_text(ring_code<RING>(ring, rel + 3u));
+        const uint32_t t4 = gt_text(ring_code<RING>(ring, rel + 4u));  // may be past the flush: then it feeds no byte (sh = 0) or only '\n''s place
+        v4u v = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
+        // the row's '\n' can only be a whole chunk's last byte (hi_emit <= 4K + 1)
+        if (off + 15u == nl) v.w = (v.w & 0x00FFFFFFu) | 0x0A000000u;
+        *reinterpret_cast<v4u *>(out0 + off) = v;
+    }
+    const uint32_t off = lane < 16u ? lane : tail_off + (lane - 16u);
+    const bool on = lane < 16u ? lane < head : (lane < 32u && lane - 16u < tail);
+    if (on) {
+        const uint32_t x = em + off;
+        const uint32_t code = ring_code<RING>(ring, e4 + (x >> 2));
+        out0[off] = (uint8_t)(off == nl ? 0x0Au : gt_text_byte(code, x & 3u));
+    }
+}
+
+// Stage a segment's keep words and their exclusive popcount prefix (once per block; needs all of
+// the block's first 256 threads and two barriers).
+__device__ __forceinline__ void stage_segment(const ScanArgs &sc, uint32_t seg, uint64_t *s_mask, uint32_t *s_pre, uint32_t tid)
+{
     const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t seg = blockIdx.x % n_seg;
-    const uint32_t row_group = blockIdx.x / n_seg;
-
-    // ---- stage this segment's keep words and their exclusive popcount prefix (once per block)
-    s_mask[tid] = sc.keep_words[(uint64_t)seg * kSegWords + tid];
+    if (tid < kSegWords) s_mask[tid] = sc.keep_words[(uint64_t)seg * kSegWords + tid];
     __syncthreads();
-    if (wave == 0u) {
+    if (tid < 64u) {
         // lane handles words 4*lane .. 4*lane+3; wave scan over the lane totals
         uint32_t c0 = __popcll(s_mask[4u * lane]), c1 = __popcll(s_mask[4u * lane + 1u]);
         uint32_t c2 = __popcll(s_mask[4u * lane + 2u]), c3 = __popcll(s_mask[4u * lane + 3u]);
@@ -80,11 +178,28 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
         if (lane == 63u) s_pre[kSegWords] = incl;
     }
     __syncthreads();
+}
+
+// A separate DENSE instantiation keeps the sparse build's registers low.
+template <bool HAS_VIDX, bool DENSE>
+__global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups)
+{
+    __shared__ uint64_t s_mask[kSegWords];
+    __shared__ uint32_t s_pre[kSegWords + 1];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kWaves][kRing];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t seg = blockIdx.x % n_seg;
+    const uint32_t row_group = blockIdx.x / n_seg;
+
+    stage_segment(sc, seg, s_mask, s_pre, tid);
 
     uint8_t *const ring = s_ring[wave];
     const uint32_t K = a.kept_count;
-    const uint32_t seg_k0 = sc.seg_rank[seg];                 // kept samples before this segment
-    const uint32_t seg_cnt = s_pre[kSegWords];                // kept samples inside it
+    const uint32_t seg_k0 = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg]);  // kept samples before this segment
+    const uint32_t seg_cnt = __builtin_amdgcn_readfirstlane(s_pre[kSegWords]);   // kept samples inside it
     const bool last_seg = seg + 1u == n_seg;
     const uint32_t seg_byte0 = seg * (kSegSamples / 4u);      // first record byte of the segment
     const uint32_t R = a.record_size;
@@ -151,56 +266,9 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
         for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
             if (live_tiles & (1u << tile)) {
                 // ---- compaction: kept codes go to the ring at their rank (src/pfile.rs:171-175)
-                uint64_t lo = (uint64_t)cur[tile].x | ((uint64_t)cur[tile].y << 32);
-                uint64_t hi = (uint64_t)cur[tile].z | ((uint64_t)cur[tile].w << 32);
-                if (tail_shift[tile] != 0u) {
-                    // record tail: the window was pulled back by tail_shift bytes; drop them
-                    const uint32_t sh8 = tail_shift[tile] * 8u;
-                    if (sh8 >= 128u) { lo = 0ull; hi = 0ull; }
-                    else if (sh8 >= 64u) { lo = hi >> (sh8 - 64u); hi = 0ull; }
-                    else { lo = (lo >> sh8) | (hi << (64u - sh8)); hi >>= sh8; }
-                }
-                uint32_t pos = pre[tile];
-                uint64_t mm = m[tile];
-                if (DENSE) {
-                    // dense masks: one record byte (4 samples) at a time; a fully kept byte becomes
-                    // one 4-byte ring write (codes spread to one per byte), partial bytes go bit-wise
-#pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        const uint32_t nib = (uint32_t)(mm >> (4 * q)) & 0xFu;
-                        if (nib == 0u) continue;
-                        const uint32_t x = (uint32_t)((q < 8 ? lo : hi) >> (8 * (q & 7))) & 0xFFu;
-                        if (nib == 0xFu) {
-                            const uint32_t d = (x & 3u) | ((x & 0xCu) << 6) | ((x & 0x30u) << 12) | ((x & 0xC0u) << 18);
-                            const uint32_t idx = pos & (kRing - 1u);
-                            if (idx <= kRing - 4u) {
-                                __builtin_memcpy(ring + idx, &d, 4);
-                            } else {
-                                ring[idx] = (uint8_t)d;
-                                ring[(idx + 1u) & (kRing - 1u)] = (uint8_t)(d >> 8);
-                                ring[(idx + 2u) & (kRing - 1u)] = (uint8_t)(d >> 16);
-                                ring[(idx + 3u) & (kRing - 1u)] = (uint8_t)(d >> 24);
-                            }
-                            pos += 4u;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                if (nib & (1u << e)) {
-                                    ring[pos & (kRing - 1u)] = (uint8_t)((x >> (2 * e)) & 3u);
-                                    pos++;
-                                }
-                            }
-                        }
-                    }
-                } else {
-                    while (mm != 0ull) {
-                        const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
-                        mm &= mm - 1ull;
-                        const uint64_t half = bit < 32u ? lo : hi;
-                        ring[pos & (kRing - 1u)] = (uint8_t)((half >> ((bit & 31u) * 2u)) & 3ull);
-                        pos++;
-                    }
-                }
+                uint64_t lo, hi;
+                window_halves(cur[tile], tail_shift[tile], lo, hi);
+                compact_lane<DENSE>(ring, 0u, lo, hi, m[tile], pre[tile]);
             }
             produced = tile_end[tile];
             const bool final = tile + 1u == kTilesPerSeg || produced == seg_cnt;
@@ -218,54 +286,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
             else
                 hi_emit = ((row_addr + avail) & ~15ull) - row_addr;     // keep the partial chunk for later
             if ((int64_t)hi_emit > (int64_t)emitted) {
-                const uint64_t lo_addr = row_addr + emitted, hi_addr = row_addr + hi_emit;
-                const uint64_t c_first = lo_addr >> 4, c_last = (hi_addr - 1ull) >> 4;
-                const uint32_t n_chunks = (uint32_t)(c_last - c_first) + 1u;
-                for (uint32_t i = lane; i < n_chunks; i += 64u) {
-                    const uint64_t caddr = (c_first + i) << 4;
-                    const int64_t q = (int64_t)(caddr - row_addr);      // row byte of the chunk start
-                    uint8_t *dst = row_out + q;
-                    // five consecutive kept codes from the ring (ranks outside this flush read stale
-                    // ring bytes: they only feed bytes that are masked out below)
-                    const int64_t k0s = q >> 2;                           // floor; may be < seg_k0 in the first chunk
-                    const uint32_t rel = (uint32_t)((int64_t)k0s - (int64_t)seg_k0);
-                    const uint32_t sh = (uint32_t)q & 3u;
-                    const uint32_t t0 = gt_text(ring_code(ring, rel));
-                    const uint32_t t1 = gt_text(ring_code(ring, rel + 1u));
-                    const uint32_t t2 = gt_text(ring_code(ring, rel + 2u));
-                    const uint32_t t3 = gt_text(ring_code(ring, rel + 3u));
-                    const uint32_t t4 = gt_text(ring_code(ring, rel + 4u));
-                    uint32_t d[4] = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
-                    // the row's '\n' (row byte 4K) if it falls into this chunk
-                    const int64_t nl = (int64_t)(4ull * K) - q;
-                    if (nl >= 0 && nl < 16) {
-#pragma unroll
-                        for (int mth = 0; mth < 4; mth++) {
-                            if ((nl >> 2) == mth) d[mth] = (d[mth] & ~(0xFFu << (8 * (nl & 3)))) | (0x0Au << (8 * (nl & 3)));
-                        }
-                    }
-                    // valid bytes of this chunk: [vb, ve) within 0..16
-                    const uint32_t vb = caddr >= lo_addr ? 0u : (uint32_t)(lo_addr - caddr);
-                    const uint32_t ve = caddr + 16ull <= hi_addr ? 16u : (uint32_t)(hi_addr - caddr);
-                    if (vb == 0u && ve == 16u) {
-                        v4u v = {d[0], d[1], d[2], d[3]};
-                        *reinterpret_cast<v4u *>(dst) = v;
-                    } else {
-                        // segment / row edge: whole dwords where possible, single bytes otherwise
-#pragma unroll
-                        for (int mth = 0; mth < 4; mth++) {
-                            const uint32_t b0 = 4u * mth;
-                            if (vb <= b0 && ve >= b0 + 4u) {
-                                *reinterpret_cast<uint32_t *>(dst + b0) = d[mth];
-                            } else {
-#pragma unroll
-                                for (int bb = 0; bb < 4; bb++) {
-                                    if (b0 + bb >= vb && b0 + bb < ve) dst[b0 + bb] = (uint8_t)(d[mth] >> (8 * bb));
-                                }
-                            }
-                        }
-                    }
-                }
+                flush_range(ring, 0u, row_out, emitted, hi_emit, seg_k0, K, lane);
                 emitted = hi_emit;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -279,24 +300,224 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// gt_scan_gather_kernel — the scan kernel for SPARSE keeps (read-dominated runs such as BASELINE
+// config 5: 1 % of 500 000 samples kept, 125 KB read and 20 KB written per variant).
+//
+// Two measured limits of gt_scan_kernel shaped it (config-5 geometry, profiles/r01_kernel_sweeps.md):
+//  (1) gfx9 counts loads and stores in ONE in-order vmcnt, and a wave's flush stores are its
+//      youngest memory operations when it comes back for the next row's record words: every row
+//      pays a store round trip.
+//  (2) the per-lane ctz loop over the lane's own keep bits runs as long as the fullest lane of the
+//      wave (3-4 rounds at 1 % kept for 0.64 kept samples per lane on average): 330 VALU
+//      instructions per 4-KiB row segment, and a CDNA SIMD retires one wave64 VALU instruction
+//      per four cycles — the kernel was VALU-bound at 46 % of the read roofline.
+// Here
+//   * the block turns its segment's keep words ONCE into a rank -> sample-index table in LDS
+//     (ballot/popcount prefix as before, then one ctz loop per block instead of one per row);
+//   * a wave keeps record words for THREE rows in registers (re-loaded three rows ahead as soon
+//     as a buffer has been parked; the loop is unrolled by three so no register copies sit
+//     between a load and its use) and, inside a batch, issues
+//     nothing but loads, so the compiler's vmcnt waits are exact there;
+//   * per row it parks the segment's record bytes in its LDS stage (one ds_write_b128 per tile)
+//     and lane r fetches kept sample r's code straight from the stage: work proportional to the
+//     number of KEPT samples, all lanes busy;
+//   * codes go to the wave's LDS ring at a RUNNING position (row n's rank r sits at
+//     n * seg_cnt + r); the whole batch (up to 48 rows) is flushed at once, two store
+//     instructions per row (flush_range), so the one store drain per batch overlaps the two rows
+//     of loads already in flight.
+// (A role split like gt_wide's — scan waves that only load, one storer wave per block — was
+// measured too: the storer's serial flush chain could not keep up with more than three scan waves.)
+// Launch precondition: every segment holds at most kGatherMaxSegCodes kept samples (host checks).
+constexpr uint32_t kGatherRing = 4096;                               // codes per wave
+constexpr uint32_t kGatherMaxRows = 48;                               // rows per batch (a store drain per batch)
+constexpr uint32_t kGatherMaxSegCodes = (kGatherRing - 8u) / 4u;     // >= 3 whole rows + the row being scanned fit the ring
+constexpr uint32_t kStageBytes = kSegSamples / 4u;                   // one row's segment of record bytes
+
+template <bool HAS_VIDX>
+__global__ __launch_bounds__(kThreads) void gt_scan_gather_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups)
+{
+    __shared__ uint64_t s_mask[kSegWords];
+    __shared__ uint32_t s_pre[kSegWords + 1];
+    __shared__ uint16_t s_idx[kGatherMaxSegCodes + 2];                // rank -> sample index inside the segment
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kWaves][kGatherRing];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t seg = blockIdx.x % n_seg;
+    const uint32_t row_group = blockIdx.x / n_seg;
+
+    stage_segment(sc, seg, s_mask, s_pre, tid);
+
+    const uint32_t K = a.kept_count;
+    const uint32_t seg_k0 = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg]);  // kept samples before this segment
+    const uint32_t seg_cnt = __builtin_amdgcn_readfirstlane(s_pre[kSegWords]);   // kept samples inside it
+    const bool last_seg = seg + 1u == n_seg;
+    const uint32_t seg_byte0 = seg * (kSegSamples / 4u);      // first record byte of the segment
+    const uint32_t R = a.record_size;
+    const uint64_t row_step = (uint64_t)row_groups * kWaves;
+    const uint64_t j0 = (uint64_t)row_group * kWaves + wave;
+    const uint64_t rows = j0 < a.n_variants ? (a.n_variants - j0 + row_step - 1ull) / row_step : 0ull;
+
+    if (seg_cnt == 0u) {
+        // nothing of this segment is kept; the last segment still owes every row its '\n' (:190)
+        if (last_seg)
+            for (uint64_t n = lane; n < rows; n += 64ull) a.out[(j0 + n * row_step) * a.out_stride + 4ull * K] = (uint8_t)'\n';
+        return;
+    }
+
+    // ---- rank -> sample index, once per block: wave w lists tile w (kTilesPerSeg == kWaves)
+    static_assert(kTilesPerSeg == (uint32_t)kWaves, "one tile per wave in the index build");
+    uint32_t live_tiles = 0u;  // tiles with at least one kept sample (wave-uniform bit set)
+    {
+        uint64_t mm = s_mask[wave * 64u + lane];
+        uint32_t pos = s_pre[wave * 64u + lane];
+        while (mm != 0ull) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            s_idx[pos++] = (uint16_t)(wave * kTileSamples + lane * 64u + bit);
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++)
+            if (__ballot(s_mask[t * 64u + lane] != 0ull) != 0ull) live_tiles |= 1u << t;
+    }
+    __syncthreads();
+    if (rows == 0ull) return;
+
+    uint8_t *const ring = s_ring[wave];
+    uint8_t *const stage = s_stage[wave];
+    uint32_t tail_shift[kTilesPerSeg];
+#pragma unroll
+    for (uint32_t t = 0; t < kTilesPerSeg; t++) {
+        const uint32_t b = seg_byte0 + t * 1024u + lane * 16u;
+        tail_shift[t] = b + 16u <= R ? 0u : min(b - (R - 16u), 16u);
+    }
+    // branch-free loads (see gt_scan_kernel); rows past the end re-load the last row, so every stage
+    // issues the same number of loads and the compiler's vmcnt bookkeeping stays exact
+    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg]) {
+        const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
+        const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
+        const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) {
+            const uint32_t b = min(seg_byte0 + t * 1024u + lane * 16u, R - 16u);
+            __builtin_memcpy(&dst[t], rec + b, 16);
+        }
+    };
+    uint32_t base = 0u;  // ring position of rank 0 of the row being scanned (mod 2^32; the ring size divides 2^32)
+    auto scan_row = [&](const v4u(&w)[kTilesPerSeg]) {
+        // park the record bytes of the live tiles (segment byte b at stage[b])
+#pragma unroll
+        for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
+            if (!(live_tiles & (1u << tile))) continue;
+            v4u x = w[tile];
+            if (tail_shift[tile] != 0u) {  // record tail: the window was pulled back; shift it into place
+                uint64_t lo, hi;
+                window_halves(x, tail_shift[tile], lo, hi);
+                x = v4u{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+            }
+            *reinterpret_cast<v4u *>(stage + tile * 1024u + lane * 16u) = x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lane r takes kept sample r (src/pfile.rs:171-175): byte idx / 4, bits 2 * (idx % 4)
+#pragma unroll 2
+        for (uint32_t r = lane; r < seg_cnt; r += 64u) {
+            const uint32_t idx = s_idx[r];
+            const uint32_t byte = stage[idx >> 2];
+            ring[(base + r) & (kGatherRing - 1u)] = (uint8_t)((byte >> ((idx & 3u) * 2u)) & 3u);
+        }
+        // the stage is rewritten by the next row: its reads above must have returned first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        base += seg_cnt;
+    };
+    auto landed = [&](const v4u(&w)[kTilesPerSeg]) {
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) asm volatile("" ::"v"(w[t].x), "v"(w[t].y), "v"(w[t].z), "v"(w[t].w));
+    };
+
+    // rows per batch: a multiple of three (the register rotation), all of them plus the row being scanned in the ring
+    const uint32_t fit = (kGatherRing - 8u) / seg_cnt - 1u;              // >= 3 by the launch precondition
+    const uint64_t batch = (uint64_t)(min(fit, kGatherMaxRows) / 3u * 3u);
+    v4u b0[kTilesPerSeg], b1[kTilesPerSeg], b2[kTilesPerSeg];
+    load_row(0ull, b0);
+    load_row(1ull, b1);
+    load_row(2ull, b2);
+    uint64_t n = 0ull;       // rows scanned
+    uint64_t flushed = 0ull; // rows written
+    while (n < rows) {
+        const uint64_t batch_end = min(rows, n + batch);
+        // ---- scan: loads and LDS only; a buffer is re-loaded (three rows ahead) as soon as it has been
+        // parked, so all three are in flight while the batch's stores drain.  Leaving the triple early
+        // only happens at the very last row.
+        for (;;) {
+            landed(b0);
+            scan_row(b0);
+            load_row(n + 3ull, b0);
+            if (++n == batch_end) break;
+            landed(b1);
+            scan_row(b1);
+            load_row(n + 3ull, b1);
+            if (++n == batch_end) break;
+            landed(b2);
+            scan_row(b2);
+            load_row(n + 3ull, b2);
+            if (++n == batch_end) break;
+        }
+        // ---- flush the batch
+        for (; flushed < n; flushed++) {
+            uint8_t *const row_out = a.out + (j0 + flushed * row_step) * a.out_stride;
+            const uint64_t lo_emit = 4ull * seg_k0;
+            const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
+            flush_range<kGatherRing>(ring, (uint32_t)flushed * seg_cnt, row_out, lo_emit, hi_emit, seg_k0, K, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
+
+// Every block walks the same number of rows, so the launch must be exactly ONE resident round: a grid
+// that exceeds residency by a few blocks runs those in a second round that takes as long as the first.
+template <typename Kern>
+static uint32_t resident_blocks(Kern kern, int threads, int num_cus)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const char *eb = getenv("PGENHIP_SCAN_BLOCKS_PER_CU");
+    if (eb && atoi(eb) > 0) per_cu = atoi(eb);
+    return (uint32_t)per_cu * (uint32_t)num_cus;
+}
 
 hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hipStream_t stream)
 {
     if (a.n_variants == 0) return hipSuccess;
     const uint32_t n_seg = (a.sample_count + kSegSamples - 1u) / kSegSamples;
     const uint32_t n_seg_eff = n_seg ? n_seg : 1u;
-    const uint64_t groups_needed = ((uint64_t)a.n_variants + kWaves - 1ull) / kWaves;
-    uint64_t groups = ((uint64_t)num_cus * 4ull + n_seg_eff - 1ull) / n_seg_eff;
-    if (groups < 1ull) groups = 1ull;
-    if (groups > groups_needed) groups = groups_needed;
-    const uint32_t grid = (uint32_t)(groups * n_seg_eff);
+    // gather kernel whenever every segment's kept codes fit its ring four times over (sparse keeps: <= 6 % of a
+    // segment); PGENHIP_SCAN_BATCH=0 forces the per-row kernel (A/B)
+    const char *es = getenv("PGENHIP_SCAN_BATCH");
+    const bool batch_ok = sc.max_seg_count <= kGatherMaxSegCodes;
+    const bool batch_kernel = batch_ok && (es ? atoi(es) != 0 : true);
     const bool dense = (uint64_t)a.kept_count * 4ull > (uint64_t)a.sample_count * 3ull;  // > 75 % kept
     void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t);
-    if (a.variant_idx)
+    if (batch_kernel)
+        kern = a.variant_idx ? gt_scan_gather_kernel<true> : gt_scan_gather_kernel<false>;
+    else if (a.variant_idx)
         kern = dense ? gt_scan_kernel<true, true> : gt_scan_kernel<true, false>;
     else
         kern = dense ? gt_scan_kernel<false, true> : gt_scan_kernel<false, false>;
+    const uint64_t groups_needed = ((uint64_t)a.n_variants + kWaves - 1ull) / kWaves;
+    uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus) / n_seg_eff;  // floor: never a partial second round
+    if (groups < 1ull) groups = 1ull;  // more segments than resident blocks (N > ~16 M samples): rounds are unavoidable
+    if (groups > groups_needed) groups = groups_needed;
+    const uint32_t grid = (uint32_t)(groups * n_seg_eff);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, sc, n_seg_eff, (uint32_t)groups);
     return hipGetLastError();
 }

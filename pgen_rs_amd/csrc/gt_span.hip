@@ -144,17 +144,6 @@ __device__ __forceinline__ Span make_span(const EmitArgs &a, const SpanParams &p
 }
 
 // ---- LDS flag words and descriptor hand-over (explicit DS instructions; see gt_wide.hip) ------
-__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)(uintptr_t)p; }
-__device__ __forceinline__ uint32_t lds_flag_read(uint32_t off)
-{
-    uint32_t v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_flag_write(uint32_t off, uint32_t value)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(off), "v"(value) : "memory");
-}
 // readfirstlane returns a signed int: widen through uint32_t
 __device__ __forceinline__ uint32_t sgpr32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t sgpr64(uint64_t v)

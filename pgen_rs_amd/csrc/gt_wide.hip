@@ -354,23 +354,6 @@ __global__ __launch_bounds__(kThreads) void gt_wide_kernel(EmitArgs a, WideParam
 constexpr int kRingSlots = 3;
 constexpr int kDescSlots = kRingSlots + 1;  // slot s % 4 was last read in step s-4, whose `done` the loader saw in step s-1
 
-// Flag words are touched with explicit DS instructions: a volatile C++ access through a generic
-// pointer would become flat_load + s_waitcnt vmcnt(0), i.e. exactly the store drain this kernel
-// exists to avoid.  The low 32 bits of a generic pointer into LDS are the LDS byte offset.
-__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)(uintptr_t)p; }
-
-__device__ __forceinline__ uint32_t lds_flag_read(uint32_t off)
-{
-    uint32_t v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
-    return v;
-}
-
-__device__ __forceinline__ void lds_flag_write(uint32_t off, uint32_t value)
-{
-    // everything this wave sent to the LDS before (slab writes / slab reads) has completed first
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(off), "v"(value) : "memory");
-}
 
 template <int NS, bool HAS_VIDX, bool NT>
 __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, WideParams p)

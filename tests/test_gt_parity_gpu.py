@@ -187,6 +187,38 @@ def test_subset_with_strides_offsets_and_gather():
         assert (got == exp).all(), f"kernel {kern}"
 
 
+@pytest.mark.parametrize("batch", ["1", "0"])
+def test_scan_kernels_many_rows_per_wave(monkeypatch, batch):
+    """Sparse-keep scan kernels with many rows per wave: the gather kernel's code ring is reused
+    across batches (12 rows each), rows end mid-triple, segments with no kept sample at the front
+    and at the back (the last segment then only owes the '\n'), a locally dense mask (falls back
+    to the per-row kernel) and a gapped variant list."""
+    monkeypatch.setenv("PGENHIP_SCAN_BLOCKS_PER_CU", "1")  # few blocks -> ~15-25 rows per wave
+    monkeypatch.setenv("PGENHIP_SCAN_BATCH", batch)
+    n = 40000  # three 16 384-sample segments, the last one partial
+    r = oracle.variant_record_size(n)
+    rng = np.random.default_rng(77)
+    masks = {
+        "1pct": np.sort(rng.choice(n, size=n // 100, replace=False)),
+        "5pct": np.sort(rng.choice(n, size=n * 5 // 100, replace=False)),      # ~820 per segment: 3 rows per batch
+        "11pct": np.sort(rng.choice(n, size=n * 11 // 100, replace=False)),    # too many for the gather kernel's ring: per-row kernel
+        "front_empty": np.sort(rng.choice(np.arange(16384, n), size=300, replace=False)),
+        "back_empty": np.sort(rng.choice(np.arange(0, 32768), size=300, replace=False)),
+        "only_middle": np.sort(rng.choice(np.arange(16384, 32768), size=500, replace=False)),
+        "locally_dense": np.concatenate([np.arange(100, 5100), np.sort(rng.choice(np.arange(20000, n), size=50, replace=False))]),
+    }
+    for label, kept in masks.items():
+        kept = kept.astype(np.uint32)
+        for v, vidx in ((6001, None), (1999, "gapped")):
+            v_file = v if vidx is None else v * 2
+            recs = rng.integers(0, 256, size=v_file * r, dtype=np.uint8)
+            idx = None if vidx is None else np.sort(rng.choice(v_file, size=v, replace=False))
+            want = oracle.decode_emit(recs, v, n, kept_idx=kept, variant_idx=idx).reshape(v, -1)
+            got, k = run_engine(recs, v, n, kept=kept, kernel=_capi.KERNEL_SCAN, variant_idx=idx)
+            exp = expect_buffer(want, v, k, 4 * k + 1, 0, got.size)
+            assert (got == exp).all(), f"mask {label} v={v} batch={batch}"
+
+
 def test_single_variant_and_zero_variants():
     n = 90
     recs = np.arange(oracle.variant_record_size(n), dtype=np.uint8)
