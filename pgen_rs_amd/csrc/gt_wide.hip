@@ -486,7 +486,10 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             }
             const uint64_t t_end = t0 == kNoItem ? 0ull : min(t0 + NS, min(((uint64_t)range + 1ull) * per_range, p.n_items));
             const uint32_t slot = (uint32_t)(step % kRingSlots);
-            v4u in0[NS], in1[NS];
+            // in0[w]: pieces 0-63 of item w; `ext`: pieces 64 and 65 of ALL items, item w in lanes 2w and 2w+1
+            // (each masked load writes only its own lanes, so seven of them share one register quad)
+            v4u in0[NS];
+            v4u ext = v4u{0u, 0u, 0u, 0u};
             uint32_t nb[NS];
             // one division per step: the step's items are consecutive, so (row, span) just counts on
             uint64_t j_it = 0ull;
@@ -500,7 +503,6 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             for (int w = 0; w < NS; w++) {
                 nb[w] = 0u;
                 in0[w] = v4u{0u, 0u, 0u, 0u};
-                in1[w] = v4u{0u, 0u, 0u, 0u};
                 // descriptor first (its ring has one slot more than the slab ring, so no wait is needed here)
                 if ((uint32_t)w >= n_here) {
                     // ~0-1 = "launch is out of work", ~0 = no item for this storer in this (last) step of a range
@@ -513,7 +515,8 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                     }
                     if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], it, t0 + (uint64_t)w);
                     if (lane < it.n_load) in0[w] = *reinterpret_cast<const v4u *>(it.base + lane * 16u);
-                    if (lane + 64u < it.n_load) in1[w] = *reinterpret_cast<const v4u *>(it.base + (lane + 64u) * 16u);
+                    if ((lane >> 1) == (uint32_t)w && 64u + (lane & 1u) < it.n_load)
+                        ext = *reinterpret_cast<const v4u *>(it.base + (64u + (lane & 1u)) * 16u);
                     // rows < n_variants <= 2^32 - 1, so row + 1 fits 32 bits
                     if (it.row_tail && (uint32_t)it.row + 1u < a.n_variants && lane == 0u)
                         nb[w] = (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                 }
                 uint8_t *slab = slabs[w][slot];
                 *reinterpret_cast<v4u *>(slab + lane * 16u) = in0[w];
-                if (lane < 4u) *reinterpret_cast<v4u *>(slab + (lane + 64u) * 16u) = in1[w];
+                if ((lane >> 1) == (uint32_t)w) *reinterpret_cast<v4u *>(slab + (64u + (lane & 1u)) * 16u) = ext;
                 if (lane == 0u) slab[kSlabBytes] = (uint8_t)nb[w];
                 if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), step + 1u);
             }
@@ -589,12 +592,17 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
         hipError_t me = hipMemsetAsync(a.work_counters, 0, 8u * 128u, stream);
         if (me != hipSuccess) return me;
         const uint64_t need = (p.n_items + 6ull) / 7ull;
-        // 3 of these 512-thread blocks are resident per CU (78 VGPRs -> 6 waves/SIMD): launch exactly that many
-        const uint64_t cap = (uint64_t)num_cus * (uint64_t)(eb ? blocks_per_cu : 3);
-        const uint32_t g = (uint32_t)(need < cap ? need : cap);
         void (*dk)(EmitArgs, WideParams);
         if (a.variant_idx) dk = nt ? gt_stream_dyn_kernel<7, true, true> : gt_stream_dyn_kernel<7, true, false>;
         else dk = nt ? gt_stream_dyn_kernel<7, false, true> : gt_stream_dyn_kernel<7, false, false>;
+        // launch exactly what is resident (62 VGPRs -> 8 waves/SIMD -> four 512-thread blocks per CU; 25 KB of LDS
+        // each): blocks beyond that would only start when the queue is already empty.  Interleaved A/B on the chr22
+        // block: 2 blocks/CU 2.12 ms, 4 blocks/CU 2.00 ms (profiles/r01_kernel_sweeps.md)
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (eb && blocks_per_cu > 0) per_cu = blocks_per_cu;
+        const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
+        const uint32_t g = (uint32_t)(need < cap ? need : cap);
         hipLaunchKernelGGL(dk, dim3(g), dim3(512), 0, stream, a, p);
         return hipGetLastError();
     }
