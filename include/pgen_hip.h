@@ -110,7 +110,11 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
  * then "GT", :157-161) + GT segment + '\n', written at d_out + d_line_off[j].
  * d_prefix_off/d_line_off are device arrays of n_variants+1 u64 with
  * d_line_off[j+1]-d_line_off[j] == prefix_len(j) + 4K + 1 (lines packed back to back);
- * max_prefix_bytes is a host-known upper bound of any prefix length (sizes the grid). */
+ * max_prefix_bytes is a host-known upper bound of any prefix length (sizes the grid).
+ * flags: PGENHIP_KERNEL_AUTO (all samples kept and sample_count >= 1024: the work-queue
+ * stream kernel writes each GT segment in place behind its prefix and a small kernel copies
+ * the prefixes; otherwise the general kernel), PGENHIP_KERNEL_ROWS or PGENHIP_KERNEL_WIDE to
+ * force one of the two (tests, A/B). */
 int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
                        const uint32_t *d_variant_idx, uint32_t n_variants,
                        const void *d_prefix_blob, const uint64_t *d_prefix_off,

@@ -335,7 +335,6 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
                        const uint64_t *d_line_off, uint64_t max_prefix_bytes,
                        void *d_out, uint32_t flags)
 {
-    (void)flags;
     int rc = bind(ctx);
     if (rc) return rc;
     EmitArgs a;
@@ -348,8 +347,23 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
     a.prefix_off = d_prefix_off;
     a.line_off = d_line_off;
     a.max_line_bytes = max_prefix_bytes + 4ull * ctx->kept_count + 1ull;
-    HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
-    return PGENHIP_OK;
+    switch (flags) {
+        case PGENHIP_KERNEL_AUTO:
+            // all samples kept and rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place
+            // behind their prefixes (+ a small prefix copy); otherwise the general kernel assembles whole lines
+            if (gt_wide_lines_applicable(a)) HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+            else HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        case PGENHIP_KERNEL_ROWS:
+            HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        case PGENHIP_KERNEL_WIDE:
+            if (!gt_wide_lines_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_WIDE needs all samples kept and sample_count >= 1024");
+            HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        default:
+            return fail(PGENHIP_ERR_BAD_ARG, "pgenhip_emit_lines supports kernel flags AUTO, ROWS and WIDE");
+    }
 }
 
 int pgenhip_wait(pgenhip_ctx *ctx)

@@ -87,22 +87,26 @@ struct Item {
 // else is computed RELATIVE to the row's first chunk in 32 bits (a row has at most 2^30 + 1 chunks),
 // because gfx9's scalar unit has no 64-bit ordered compare — every 64-bit min/max becomes a VALU
 // compare plus a round trip through VCC, and the loader wave computes seven items per step.
-template <bool HAS_VIDX>
+// LINES (full VCF body lines, src/pfile.rs:156-192): row j's GT segment starts behind its own prefix, at
+// line_off[j] + prefix length — any byte offset — and the bytes around it belong to the prefixes, so a
+// row owns the chunk that holds its first GT byte (like row 0 of the dense stream) and writes only
+// its own bytes of its first and last chunk.
+template <bool HAS_VIDX, bool LINES = false>
 __device__ __forceinline__ Item make_item_at(const EmitArgs &a, const WideParams &p, uint64_t j, uint32_t k)
 {
     Item it;
     const uint64_t S = p.row_bytes;
-    const uint64_t row_start = j * S;
+    const uint64_t row_start = LINES ? a.line_off[j] + (a.prefix_off[j + 1ull] - a.prefix_off[j]) : j * S;
     // row j owns the chunks whose first byte lies in [j*S, (j+1)*S); row 0 also the chunk that
     // holds stream byte 0.  Spans are cut on 64-chunk (1 KiB) boundaries of the chunk grid so every
     // store instruction of a wave covers eight WHOLE 128-B lines (except at the two row ends).
-    const uint64_t g_first = j == 0 ? (uint64_t)(p.head >> 4) : (row_start + p.head + 15ull) >> 4;
+    const uint64_t g_first = (LINES || j == 0) ? (row_start + p.head) >> 4 : (row_start + p.head + 15ull) >> 4;
     const uint64_t g_end = (row_start + S + p.head + 15ull) >> 4;
     const int32_t row_chunks = (int32_t)(uint32_t)(g_end - g_first);
     const int32_t base_rel = (int32_t)(k * kSpanChunks) - (int32_t)((uint32_t)g_first & 63u);  // span base - g_first
     const int32_t end_rel = min(row_chunks, base_rel + (int32_t)kSpanChunks);
     const int32_t g0_rel = max(base_rel, 0);
-    // row-relative byte offset of chunk g_first: 0..15 (row 0: -(head & 15)); exact modulo 2^32
+    // row-relative byte offset of chunk g_first: 0..15 (row 0 and LINES: -15..0); exact modulo 2^32
     const int32_t row_c_first = (int32_t)((uint32_t)g_first * 16u - p.head - (uint32_t)row_start);
     it.row = j;
     it.g0 = g_first + (uint64_t)(uint32_t)g0_rel;
@@ -175,7 +179,7 @@ __device__ __forceinline__ Item desc_get_item(const uint8_t *x)
 // j+1 (needed by the chunk that holds row j's '\n') was parked at slab[kSlabBytes] by the loader
 // wave, so this wave never issues a global load (gfx9 has one in-order vmcnt for loads and stores:
 // a wave that waits for a load also drains all its older stores).
-template <bool HAS_VIDX, bool NT, bool NEXT_IN_SLAB>
+template <bool HAS_VIDX, bool NT, bool NEXT_IN_SLAB, bool LINES = false>
 __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p, const Item &it,
                                           const uint8_t *slab, uint32_t lane)
 {
@@ -194,6 +198,8 @@ __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p
     uint8_t *const span_ptr = chunk0 + (it.g0 - it.lead) * 16ull + lane * 16u;  // lane's chunk in step 0
     const uint32_t first_plain = it.lead + (head_chunk ? 1u : 0u);               // steps at/after this position ...
     const uint32_t end_plain = it.lead + n_interior;                              // ... and before this one are all-interior
+    // the item holds the row's last chunk (the descriptor hand-over does not carry Item::row_tail)
+    const bool row_tail = it.cnt != 0u && it.c_first + 16ll * (int64_t)it.cnt >= (int64_t)S;
     const uint32_t pshift = ((phase >> 2) & 3u) * 2u;                             // bit offset of sample k0 in its byte (row-uniform)
     const uint32_t psh = phase & 3u;                                              // byte phase of the text (row-uniform)
     const int32_t slab_b0 = bf + delta - (int32_t)it.lead + (int32_t)lane;        // slab offset of the lane's window in step 0
@@ -233,7 +239,14 @@ __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p
         // store instruction (a second, one-lane store per row was 8 % of the kernel's store instructions)
         u32x4 v = gt_text16_from_window(window, (int64_t)phase);
         bool whole = i < n_interior && !(head_chunk && i == 0u);
-        if (!whole) {
+        if (LINES) {
+            // a row's first and last chunk are shared with the prefixes around it: only a last chunk whose
+            // '\n' is its 16th byte is whole; the other two are written byte-wise below (edge bytes)
+            if (!whole && i + 1u == it.cnt && row_tail && (int64_t)gt_bytes - (it.c_first + 16ll * (int64_t)i) == 15) {
+                v.w = (v.w & 0x00FFFFFFu) | 0x0A000000u;
+                whole = true;
+            }
+        } else if (!whole) {
             // ---- row tail: the chunk holds '\n' at byte nl (and the head of row j+1 behind it)
             const int64_t c = it.c_first + 16ll * (int64_t)i;
             const int64_t o = (int64_t)((it.g0 + i) * 16ull) - (int64_t)p.head;
@@ -286,6 +299,28 @@ __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p
             }
         }
         if (whole) store_chunk<NT>(dst, v);
+    }
+    if (LINES) {
+        // ---- edge bytes: the row's own bytes of its first chunk (lanes 0-15) and of its last chunk
+        // (lanes 16-31) in ONE byte-store instruction, read straight from the staged record bytes
+        const bool head_edge = head_chunk && it.cnt != 0u;
+        const uint32_t i_tail = it.cnt - 1u;
+        const int64_t c_tail = it.c_first + 16ll * (int64_t)i_tail;
+        const uint32_t nl = (uint32_t)((int64_t)gt_bytes - c_tail);                 // byte of '\n' in the last chunk (row_tail)
+        const bool tail_edge = row_tail && nl < 15u;
+        if (head_edge || tail_edge) {
+            const bool hl = lane < 16u;
+            const uint32_t b = lane & 15u;
+            const int64_t c = hl ? it.c_first : c_tail;                               // row byte of the chunk's byte 0
+            const bool on = hl ? (head_edge && (int32_t)b >= -(int32_t)it.c_first) : (lane < 32u && tail_edge && b <= nl);
+            if (on) {
+                const uint32_t x = ((uint32_t)c & 15u) + b;                           // row byte = 16 * (c >> 4) + x
+                const int32_t rb = (int32_t)(c >> 4) + (int32_t)(x >> 4);              // record byte of that sample
+                const uint32_t code = ((uint32_t)slab[rb + delta] >> (((x >> 2) & 3u) * 2u)) & 3u;
+                const uint32_t ch = (!hl && b == nl) ? 0x0Au : gt_text_byte(code, x & 3u);
+                chunk0[(it.g0 + (hl ? 0u : i_tail)) * 16ull + b] = (uint8_t)ch;
+            }
+        }
     }
 }
 
@@ -439,7 +474,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, Wi
 // head word (heads live 128 B apart; ~10 claims/us per word, far below the ~88/us a word takes)
 // and steals from the next range when its own is drained.  Every block therefore runs until the
 // whole launch is out of work and all of them finish within one step of each other.
-template <int NS, bool HAS_VIDX, bool NT>
+template <int NS, bool HAS_VIDX, bool NT, bool LINES = false>
 __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a, WideParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][kRingSlots][kSlabBytes + kSlabExtra];
@@ -508,7 +543,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                     // ~0-1 = "launch is out of work", ~0 = no item for this storer in this (last) step of a range
                     if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], Item{}, t0 == kNoItem ? kNoItem - 1ull : kNoItem);
                 } else {
-                    const Item it = make_item_at<HAS_VIDX>(a, p, j_it, k_it);
+                    const Item it = make_item_at<HAS_VIDX, LINES>(a, p, j_it, k_it);
                     if (++k_it == p.spans_per_row) {
                         k_it = 0u;
                         j_it++;
@@ -518,7 +553,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                     if ((lane >> 1) == (uint32_t)w && 64u + (lane & 1u) < it.n_load)
                         ext = *reinterpret_cast<const v4u *>(it.base + (64u + (lane & 1u)) * 16u);
                     // rows < n_variants <= 2^32 - 1, so row + 1 fits 32 bits
-                    if (it.row_tail && (uint32_t)it.row + 1u < a.n_variants && lane == 0u)
+                    if (!LINES && it.row_tail && (uint32_t)it.row + 1u < a.n_variants && lane == 0u)
                         nb[w] = (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
                 }
             }
@@ -550,10 +585,30 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             if (t == kNoItem - 1ull) break;          // the loader found every range drained
             if (t != kNoItem) {                       // kNoItem: this storer has no item in this (last) step of a range
                 const Item it = desc_get_item(desc);
-                emit_item<HAS_VIDX, NT, true>(a, p, it, slab, lane);
+                emit_item<HAS_VIDX, NT, true, LINES>(a, p, it, slab, lane);
             }
             if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), step + 1u);
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// copy_prefixes_kernel — LINES mode: line j's prefix bytes (pvar fields + "GT", src/pfile.rs:157-161)
+// from the blob to out + line_off[j].  1-2 % of the output bytes; a quarter wave per line so four
+// lines are in flight per wave, byte granular because the neighbouring GT bytes belong to the stream
+// kernel's waves.
+__global__ __launch_bounds__(256) void copy_prefixes_kernel(EmitArgs a)
+{
+    const uint32_t sub = threadIdx.x & 15u;
+    const uint64_t quarter = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t n_quarters = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t j = quarter; j < a.n_variants; j += n_quarters) {
+        const uint64_t p0 = a.prefix_off[j];
+        const uint64_t len = a.prefix_off[j + 1ull] - p0;
+        const uint8_t *__restrict__ src = a.prefix_blob + p0;
+        uint8_t *__restrict__ dst = a.out + a.line_off[j];
+        for (uint64_t b = sub; b < len; b += 16ull) dst[b] = src[b];
     }
 }
 
@@ -564,6 +619,13 @@ bool gt_wide_applicable(const EmitArgs &a)
     // rows of >= 4 KiB keep a wave's span reasonably full; R >= 16 for the clamped window reads
     return a.kept_idx == nullptr && a.line_off == nullptr && a.sample_count >= 1024u &&
            (a.n_variants <= 1 || a.out_stride == 4ull * a.kept_count + 1ull);
+}
+
+bool gt_wide_lines_applicable(const EmitArgs &a)
+{
+    // full lines through the work-queue stream kernel: all samples kept, rows of >= 4 KiB, queue heads present
+    return a.kept_idx == nullptr && a.line_off != nullptr && a.prefix_off != nullptr && a.sample_count >= 1024u &&
+           a.work_counters != nullptr;
 }
 
 hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
@@ -588,13 +650,18 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
     const int stream_ns = es ? atoi(es) : 7;  // default: 1 loader + 7 storer waves (interleaved A/B: profiles/r01_kernel_sweeps.md)
     const char *ed = getenv("PGENHIP_WIDE_DYN");
     const bool dyn = ed ? atoi(ed) != 0 : true;  // work queue on by default (interleaved A/B: +9 % on the chr22 block)
-    if (stream_ns == 7 && dyn && a.work_counters) {
+    if ((stream_ns == 7 && dyn && a.work_counters) || a.line_off) {
         hipError_t me = hipMemsetAsync(a.work_counters, 0, 8u * 128u, stream);
         if (me != hipSuccess) return me;
         const uint64_t need = (p.n_items + 6ull) / 7ull;
         void (*dk)(EmitArgs, WideParams);
-        if (a.variant_idx) dk = nt ? gt_stream_dyn_kernel<7, true, true> : gt_stream_dyn_kernel<7, true, false>;
-        else dk = nt ? gt_stream_dyn_kernel<7, false, true> : gt_stream_dyn_kernel<7, false, false>;
+        if (a.line_off) {
+            if (a.variant_idx) dk = nt ? gt_stream_dyn_kernel<7, true, true, true> : gt_stream_dyn_kernel<7, true, false, true>;
+            else dk = nt ? gt_stream_dyn_kernel<7, false, true, true> : gt_stream_dyn_kernel<7, false, false, true>;
+        } else {
+            if (a.variant_idx) dk = nt ? gt_stream_dyn_kernel<7, true, true> : gt_stream_dyn_kernel<7, true, false>;
+            else dk = nt ? gt_stream_dyn_kernel<7, false, true> : gt_stream_dyn_kernel<7, false, false>;
+        }
         // launch exactly what is resident (62 VGPRs -> 8 waves/SIMD -> four 512-thread blocks per CU; 25 KB of LDS
         // each): blocks beyond that would only start when the queue is already empty.  Interleaved A/B on the chr22
         // block: 2 blocks/CU 2.12 ms, 4 blocks/CU 2.00 ms (profiles/r01_kernel_sweeps.md)
@@ -604,6 +671,12 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
         const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
         const uint32_t g = (uint32_t)(need < cap ? need : cap);
         hipLaunchKernelGGL(dk, dim3(g), dim3(512), 0, stream, a, p);
+        if (a.line_off && a.prefix_blob) {
+            // the prefixes: disjoint bytes, same stream, any order
+            const uint64_t blocks_needed = ((uint64_t)a.n_variants * 16ull + 255ull) / 256ull;
+            const uint64_t pcap = (uint64_t)num_cus * 8ull;
+            hipLaunchKernelGGL(copy_prefixes_kernel, dim3((uint32_t)(blocks_needed < pcap ? blocks_needed : pcap)), dim3(256), 0, stream, a);
+        }
         return hipGetLastError();
     }
     if (stream_ns == 3 || stream_ns == 7) {

@@ -255,6 +255,42 @@ def test_emit_lines_vs_oracle(n, kept_mod):
     assert (got[want.size :] == SENTINEL).all()
 
 
+@pytest.mark.parametrize("n,v", [(1024, 37), (2504, 700), (4099, 300), (70001, 40)])
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_ROWS, _capi.KERNEL_WIDE])
+def test_emit_lines_stream_kernel(n, v, kernel):
+    """Full lines through the work-queue stream kernel (PGENHIP_KERNEL_WIDE) and the general kernel:
+    prefixes of 0..40 bytes (so GT segments start at every byte phase and neighbouring lines share
+    16-byte chunks), an unaligned output pointer, a gapped variant list, several spans per row
+    (N = 70 001), many rows per block; sentinel bytes around the output must stay untouched."""
+    rng = np.random.default_rng(500 + n)
+    r = oracle.variant_record_size(n)
+    v_file = v + 11
+    recs = rng.integers(0, 256, size=v_file * r, dtype=np.uint8)
+    vidx = np.sort(rng.choice(v_file, size=v, replace=False))
+    prefixes = []
+    for i in range(v):
+        ln = int(rng.integers(0, 41)) if i % 7 else 0
+        prefixes.append(bytes(rng.integers(33, 127, size=ln, dtype=np.uint8)))
+    blob = np.frombuffer(b"".join(prefixes) + b"!", dtype=np.uint8)
+    poff = np.cumsum([0] + [len(q) for q in prefixes]).astype(np.int64)
+    loff = np.cumsum([0] + [len(q) + 4 * n + 1 for q in prefixes]).astype(np.int64)
+    want = oracle.emit_lines(recs, v, n, blob, poff.astype(np.uint64), loff.astype(np.uint64), variant_idx=vidx)
+    for out_offset in (0, 5):
+        with pgen_rs_amd.GtEngine(n, device=0) as eng:
+            out = torch.full((out_offset + int(loff[-1]) + 48,), SENTINEL, dtype=torch.uint8, device=DEV)
+            eng.emit_lines(torch.from_numpy(recs).to(DEV), v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV),
+                           torch.from_numpy(loff).to(DEV), 40, out[out_offset:],
+                           variant_idx=torch.tensor(vidx, dtype=torch.int32, device=DEV), kernel=kernel)
+            eng.wait()
+            got = out.cpu().numpy()
+        assert (got[:out_offset] == SENTINEL).all()
+        body = got[out_offset : out_offset + want.size]
+        if bytes(body) != want.tobytes():
+            bad = np.flatnonzero(body != want)
+            raise AssertionError(f"n={n} kernel={kernel} offset={out_offset}: {bad.size} bytes differ, first at {bad[:5]}")
+        assert (got[out_offset + want.size :] == SENTINEL).all()
+
+
 def test_device_synth_matches_oracle_twin():
     for n, v, first, stride_pad, dirty in [(2504, 33, 0, 0, False), (10007, 9, 123, 3, True), (5, 4, 2**31, 0, False), (500000, 2, 999_999, 0, False)]:
         r = oracle.variant_record_size(n)
