@@ -91,12 +91,14 @@ struct Item {
 // line_off[j] + prefix length — any byte offset — and the bytes around it belong to the prefixes, so a
 // row owns the chunk that holds its first GT byte (like row 0 of the dense stream) and writes only
 // its own bytes of its first and last chunk.
+// (`lines_row_start` = line_off[j] + prefix length, fetched by the caller: one coalesced load per step for all of
+// a step's rows instead of two dependent round trips per item)
 template <bool HAS_VIDX, bool LINES = false>
-__device__ __forceinline__ Item make_item_at(const EmitArgs &a, const WideParams &p, uint64_t j, uint32_t k)
+__device__ __forceinline__ Item make_item_at(const EmitArgs &a, const WideParams &p, uint64_t j, uint32_t k, uint64_t lines_row_start = 0ull)
 {
     Item it;
     const uint64_t S = p.row_bytes;
-    const uint64_t row_start = LINES ? a.line_off[j] + (a.prefix_off[j + 1ull] - a.prefix_off[j]) : j * S;
+    const uint64_t row_start = LINES ? lines_row_start : j * S;
     // row j owns the chunks whose first byte lies in [j*S, (j+1)*S); row 0 also the chunk that
     // holds stream byte 0.  Spans are cut on 64-chunk (1 KiB) boundaries of the chunk grid so every
     // store instruction of a wave covers eight WHOLE 128-B lines (except at the two row ends).
@@ -521,10 +523,13 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             }
             const uint64_t t_end = t0 == kNoItem ? 0ull : min(t0 + NS, min(((uint64_t)range + 1ull) * per_range, p.n_items));
             const uint32_t slot = (uint32_t)(step % kRingSlots);
-            // in0[w]: pieces 0-63 of item w; `ext`: pieces 64 and 65 of ALL items, item w in lanes 2w and 2w+1
-            // (each masked load writes only its own lanes, so seven of them share one register quad)
+            // in0[w]: pieces 0-63 of item w; `ext`: pieces 64 and 65 of ALL items, item w in lanes 2w and 2w+1, fetched
+            // by ONE load after the item loop (seven masked loads into one register quad would each wait for the
+            // one before: the compiler orders writes to a register it cannot prove lane-disjoint)
             v4u in0[NS];
             v4u ext = v4u{0u, 0u, 0u, 0u};
+            const uint8_t *ext_addr = a.records;
+            bool ext_on = false;
             uint32_t nb[NS];
             // one division per step: the step's items are consecutive, so (row, span) just counts on
             uint64_t j_it = 0ull;
@@ -534,6 +539,21 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                 k_it = p.spans_per_row == 1u ? 0u : (uint32_t)(t0 - j_it * p.spans_per_row);
             }
             const uint32_t n_here = t0 == kNoItem ? 0u : (uint32_t)(t_end - t0);  // items of this step (<= NS)
+            // LINES: where each row's GT segment starts.  A step's items cover at most NS consecutive rows:
+            // lane r fetches line_off / prefix_off of row j_it + r (one coalesced load each) and keeps that row's
+            // start; items pick theirs with v_readlane.  The value is passed through an asm move so that the
+            // compiler does not tie the later readlanes to the loads (it would wait for the previous item's
+            // record load before every item).
+            const uint64_t j_step = j_it;
+            uint32_t rs_lo = 0u, rs_hi = 0u;
+            if (LINES && t0 != kNoItem) {
+                const uint64_t jr = min(j_it + (uint64_t)lane, (uint64_t)a.n_variants);  // both arrays have n_variants + 1 entries
+                const uint64_t lo_v = a.line_off[jr];
+                const uint64_t po_v = a.prefix_off[jr];
+                const uint64_t po_next = __shfl_down((unsigned long long)po_v, 1, 64);
+                const uint64_t rs = lo_v + (po_next - po_v);
+                asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(rs_lo), "=v"(rs_hi) : "v"((uint32_t)rs), "v"((uint32_t)(rs >> 32)));
+            }
 #pragma unroll
             for (int w = 0; w < NS; w++) {
                 nb[w] = 0u;
@@ -543,20 +563,30 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                     // ~0-1 = "launch is out of work", ~0 = no item for this storer in this (last) step of a range
                     if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], Item{}, t0 == kNoItem ? kNoItem - 1ull : kNoItem);
                 } else {
-                    const Item it = make_item_at<HAS_VIDX, LINES>(a, p, j_it, k_it);
+                    uint64_t row_start = 0ull;
+                    if (LINES) {
+                        const uint32_t r = (uint32_t)(j_it - j_step);  // < NS
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)rs_hi, (int)r);
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)rs_lo, (int)r);
+                        row_start = ((uint64_t)hi << 32) | (uint64_t)lo;
+                    }
+                    const Item it = make_item_at<HAS_VIDX, LINES>(a, p, j_it, k_it, row_start);
                     if (++k_it == p.spans_per_row) {
                         k_it = 0u;
                         j_it++;
                     }
                     if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], it, t0 + (uint64_t)w);
                     if (lane < it.n_load) in0[w] = *reinterpret_cast<const v4u *>(it.base + lane * 16u);
-                    if ((lane >> 1) == (uint32_t)w && 64u + (lane & 1u) < it.n_load)
-                        ext = *reinterpret_cast<const v4u *>(it.base + (64u + (lane & 1u)) * 16u);
+                    if ((lane >> 1) == (uint32_t)w) {
+                        ext_addr = it.base + (64u + (lane & 1u)) * 16u;
+                        ext_on = 64u + (lane & 1u) < it.n_load;
+                    }
                     // rows < n_variants <= 2^32 - 1, so row + 1 fits 32 bits
                     if (!LINES && it.row_tail && (uint32_t)it.row + 1u < a.n_variants && lane == 0u)
                         nb[w] = (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
                 }
             }
+            if (ext_on) ext = *reinterpret_cast<const v4u *>(ext_addr);
             if (t0 != kNoItem) pending = issue_claim(range);  // for the next step; read at the top of the loop
 #pragma unroll
             for (int w = 0; w < NS; w++) {
