@@ -1,6 +1,6 @@
 """Probe: kept-subset kernels (scan vs list gather) at config-5 geometry and other densities."""
 import os, sys, statistics
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import numpy as np
 import torch
 import pgen_rs_amd
