@@ -3,7 +3,12 @@
 
 namespace pgenhost {
 
-TsvReader::TsvReader(const std::string &data, size_t start, char delimiter) : data_(data), pos_(start), delim_(delimiter)
+TsvReader::TsvReader(const TsvReader &parent, size_t start, size_t end)
+    : data_(parent.data_), pos_(start), end_(end), delim_(parent.delim_), headers_(parent.headers_)
+{
+}
+
+TsvReader::TsvReader(const std::string &data, size_t start, char delimiter) : data_(data), pos_(start), end_(data.size()), delim_(delimiter)
 {
     // has_headers(true): the first record is the header row (src/pfile.rs:280, :84, :317)
     if (!read_record(headers_)) headers_.clear();
@@ -24,7 +29,7 @@ bool TsvReader::next(StringRecord &out)
 bool TsvReader::read_record(StringRecord &out)
 {
     out.clear();
-    const size_t n = data_.size();
+    const size_t n = end_;
     // skip empty lines
     while (pos_ < n && (data_[pos_] == '\n' || data_[pos_] == '\r')) {
         if (data_[pos_] == '\n') line_++;

@@ -29,16 +29,24 @@ class TsvReader {
     // Parses `data` starting at byte `start` (the reference seeks the file to just after the '#'
     // of the column-header line, src/pfile.rs:271-273).  The first record becomes the headers.
     TsvReader(const std::string &data, size_t start, char delimiter = '\t');
+    // A reader over the data records in [start, end) of a file whose header row was already read
+    // by `parent` (parallel filtering: [start, end) must begin and end on record boundaries).
+    TsvReader(const TsvReader &parent, size_t start, size_t end);
 
     const StringRecord &headers() const { return headers_; }
     // Next data record; false at end of input.  Throws CsvError on a ragged record.
     bool next(StringRecord &out);
     size_t records_read() const { return n_records_; }
+    // Byte range not yet consumed, and the text itself (for splitting the rest between threads).
+    size_t position() const { return pos_; }
+    size_t end_position() const { return end_; }
+    const std::string &data() const { return data_; }
 
   private:
     bool read_record(StringRecord &out);
     const std::string &data_;
     size_t pos_;
+    size_t end_;
     char delim_;
     StringRecord headers_;
     size_t n_records_ = 0;

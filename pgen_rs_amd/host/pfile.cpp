@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <deque>
@@ -165,16 +166,19 @@ uint64_t Pfile::find_metadata_file_header_start(const std::string &data)
 }
 
 // :312-335
-Pfile::IdxRecords Pfile::filter_metadata(TsvReader &reader, const std::optional<std::string> &query)
+namespace {
+
+// src/pfile.rs:312-335 for the records of one reader, indices starting at `first_idx`.
+Pfile::IdxRecords filter_records(TsvReader &reader, const std::optional<std::string> &query, size_t first_idx)
 {
-    IdxRecords kept;
+    Pfile::IdxRecords kept;
     std::optional<Expr> expr;
     if (query) {
         expr.emplace(*query);
         expr->bind(reader.headers());
     }
     StringRecord rcd;
-    size_t idx = 0;
+    size_t idx = first_idx;
     while (reader.next(rcd)) {
         const bool keep = expr ? expr->eval_boolean(rcd) : true;  // :321-329
         if (keep) kept.emplace_back(idx, rcd);                    // :330-332
@@ -183,7 +187,69 @@ Pfile::IdxRecords Pfile::filter_metadata(TsvReader &reader, const std::optional<
     return kept;
 }
 
-// :78-102
+}  // namespace
+
+// N2: the reference walks the metadata file on one thread (2.7 s of its chr22 runs,
+// README.md:164-168).  Records are independent, so a big file without quotes — a quoted field may
+// hold a line break, which would make a split point ambiguous — is cut at line ends into one piece
+// per thread; every piece is parsed and filtered like the whole (same header row, same expression),
+// and the kept records are concatenated in file order with their indices shifted by the number of
+// records before the piece.  Any error re-runs the serial walk so that the message (record and line
+// numbers) is the one the serial reader gives.
+Pfile::IdxRecords Pfile::filter_metadata(TsvReader &reader, const std::optional<std::string> &query)
+{
+    const std::string &data = reader.data();
+    const size_t begin = reader.position(), end = reader.end_position();
+    const size_t kMinBytesPerThread = 1u << 20;
+    size_t n_threads = std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), 16u, (end - begin) / kMinBytesPerThread});
+    if (const char *e = getenv("PGENHIP_FILTER_THREADS")) n_threads = (size_t)std::max(1, atoi(e));
+    if (n_threads < 2 || begin >= end || memchr(data.data() + begin, '"', end - begin) != nullptr)
+        return filter_records(reader, query, 0);
+
+    // piece boundaries: just behind a '\n' (files that end records with a lone '\r' stay in one piece)
+    std::vector<size_t> cuts{begin};
+    for (size_t t = 1; t < n_threads; t++) {
+        const size_t want = begin + (end - begin) / n_threads * t;
+        if (want <= cuts.back()) continue;
+        const void *nl = memchr(data.data() + want, '\n', end - want);
+        if (!nl) break;
+        const size_t cut = (size_t)(static_cast<const char *>(nl) - data.data()) + 1u;
+        if (cut > cuts.back() && cut < end) cuts.push_back(cut);
+    }
+    cuts.push_back(end);
+    const size_t n_pieces = cuts.size() - 1u;
+    if (n_pieces < 2) return filter_records(reader, query, 0);
+
+    std::vector<IdxRecords> kept(n_pieces);
+    std::vector<size_t> n_records(n_pieces, 0);
+    std::vector<char> failed(n_pieces, 0);
+    std::vector<std::thread> workers;
+    for (size_t t = 0; t < n_pieces; t++) {
+        workers.emplace_back([&, t] {
+            try {
+                TsvReader piece(reader, cuts[t], cuts[t + 1u]);
+                kept[t] = filter_records(piece, query, 0);  // indices local to the piece
+                n_records[t] = piece.records_read();
+            } catch (...) {
+                failed[t] = 1;
+            }
+        });
+    }
+    for (auto &w : workers) w.join();
+    if (std::find(failed.begin(), failed.end(), (char)1) != failed.end()) return filter_records(reader, query, 0);  // throws the serial error
+
+    size_t total = 0;
+    for (const auto &k : kept) total += k.size();
+    IdxRecords all;
+    all.reserve(total);
+    size_t base = 0;
+    for (size_t t = 0; t < n_pieces; t++) {
+        for (auto &kv : kept[t]) all.emplace_back(kv.first + base, std::move(kv.second));
+        base += n_records[t];
+    }
+    return all;
+}
+
 void Pfile::query_metadata(TsvReader &reader, const std::optional<std::string> &query, const std::string &f_string, std::string &out)
 {
     std::optional<Expr> filter;

@@ -151,3 +151,43 @@ def test_default_output_name_and_no_gpu_is_loud(basic1, tmp_path):
         pytest.skip("needs a box without a GPU")
     p = run("filter", str(basic1), "--include-var", 'ID == "rs8100066"')
     assert p.returncode == 101 and b"no" in p.stderr.lower()
+
+
+def test_parallel_metadata_filter_matches_serial(tmp_path):
+    """N2: the pvar walk split between threads keeps the same records with the same indices as
+    the serial walk (PGENHIP_FILTER_THREADS=1), reports the same error for a ragged row in a late
+    piece, and stays serial when the file has a quote (a quoted field may hold a line break)."""
+    import os
+
+    rows = [b"#CHROM\tPOS\tID\tREF\tALT\tINFO"]
+    for i in range(150_000):
+        alt = b"G" if i % 3 == 0 else (b"T" if i % 3 == 1 else b"C")
+        rows.append(b"22\t%d\tsnp%d\tA\t%s\t%s" % (16050000 + 7 * i, i, alt, b"x" * (i % 23)))
+    body = b"\n".join(rows) + b"\n"
+    pre = write_meta(tmp_path, body, PSAM, n=3, v=150_000)
+
+    def dry(threads, expr='ALT == "G" || POS == "16050007"'):
+        env = dict(os.environ)
+        if threads is None:
+            env.pop("PGENHIP_FILTER_THREADS", None)
+        else:
+            env["PGENHIP_FILTER_THREADS"] = str(threads)
+        return subprocess.run([str(CLI), "filter", str(pre), "--include-var", expr, "--dry-run", "-o", str(tmp_path / "o.vcf")],
+                              capture_output=True, env=env)
+
+    serial = dry(1)
+    assert serial.returncode == 0, serial.stderr
+    info = json.loads(serial.stdout)
+    assert info["variants_kept"] == 50_001
+    for threads in (None, 2, 5, 16):
+        par = dry(threads)
+        assert par.returncode == 0 and par.stdout == serial.stdout, threads
+    # a ragged record near the end: same exit code and message from both walks
+    (tmp_path / "t.pvar").write_bytes(body + b"22\t1\tbad\n")
+    a, b = dry(1), dry(7)
+    assert a.returncode == b.returncode == 101 and a.stderr == b.stderr and b"fields" in a.stderr
+    # a quoted field with an embedded line break: one record, whatever the thread count
+    (tmp_path / "t.pvar").write_bytes(body + b'22\t2\t"q\nq"\tA\tG\tz\n')
+    a, b = dry(1), dry(7)
+    assert a.returncode == b.returncode == 0 and a.stdout == b.stdout
+    assert json.loads(a.stdout)["variants_kept"] == 50_002
