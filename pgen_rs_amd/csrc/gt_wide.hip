@@ -181,7 +181,7 @@ __device__ __forceinline__ Item desc_get_item(const uint8_t *x)
 // j+1 (needed by the chunk that holds row j's '\n') was parked at slab[kSlabBytes] by the loader
 // wave, so this wave never issues a global load (gfx9 has one in-order vmcnt for loads and stores:
 // a wave that waits for a load also drains all its older stores).
-template <bool HAS_VIDX, bool NT, bool NEXT_IN_SLAB, bool LINES = false>
+template <bool HAS_VIDX, bool NT, bool NEXT_IN_SLAB, bool LINES = false, int BURST = 1>
 __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p, const Item &it,
                                           const uint8_t *slab, uint32_t lane)
 {
@@ -205,9 +205,30 @@ __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p
     const uint32_t pshift = ((phase >> 2) & 3u) * 2u;                             // bit offset of sample k0 in its byte (row-uniform)
     const uint32_t psh = phase & 3u;                                              // byte phase of the text (row-uniform)
     const int32_t slab_b0 = bf + delta - (int32_t)it.lead + (int32_t)lane;        // slab offset of the lane's window in step 0
-#pragma unroll 4
     for (uint32_t u = 0; u < kSpanChunks / 64u; u++) {
         if (u * 64u >= it.lead + it.cnt) break;
+        if (BURST > 1 && u * 64u >= first_plain && (u + (uint32_t)BURST) * 64u <= end_plain) {
+            // BURST plain steps: all the text first, then the stores back to back, so that the memory system gets
+            // BURST KiB of one contiguous run at once instead of 1 KiB every few hundred cycles
+            u32x4 vb[BURST];
+#pragma unroll
+            for (int q = 0; q < BURST; q++) {
+                uint16_t h;
+                __builtin_memcpy(&h, slab + slab_b0 + (int32_t)((u + (uint32_t)q) * 64u), 2);
+                const uint32_t w = (uint32_t)h >> pshift;
+                const uint32_t t0 = gt_text(w & 3u), t1 = gt_text((w >> 2) & 3u), t2 = gt_text((w >> 4) & 3u);
+                const uint32_t t3 = gt_text((w >> 6) & 3u), t4 = gt_text((w >> 8) & 3u);
+                vb[q].x = funnel_bytes(t0, t1, psh);
+                vb[q].y = funnel_bytes(t1, t2, psh);
+                vb[q].z = funnel_bytes(t2, t3, psh);
+                vb[q].w = funnel_bytes(t3, t4, psh);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < BURST; q++) store_chunk<NT>(span_ptr + (u + (uint32_t)q) * 1024u, vb[q]);
+            u += (uint32_t)BURST - 1u;
+            continue;
+        }
         if (u * 64u >= first_plain && u * 64u + 64u <= end_plain) {
             // every lane's chunk lies inside the row's text and inside the record: no clamps, no masks
             uint16_t h;
@@ -476,7 +497,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, Wi
 // head word (heads live 128 B apart; ~10 claims/us per word, far below the ~88/us a word takes)
 // and steals from the next range when its own is drained.  Every block therefore runs until the
 // whole launch is out of work and all of them finish within one step of each other.
-template <int NS, bool HAS_VIDX, bool NT, bool LINES = false>
+template <int NS, bool HAS_VIDX, bool NT, bool LINES = false, int BURST = 1>
 __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a, WideParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][kRingSlots][kSlabBytes + kSlabExtra];
@@ -615,7 +636,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             if (t == kNoItem - 1ull) break;          // the loader found every range drained
             if (t != kNoItem) {                       // kNoItem: this storer has no item in this (last) step of a range
                 const Item it = desc_get_item(desc);
-                emit_item<HAS_VIDX, NT, true, LINES>(a, p, it, slab, lane);
+                emit_item<HAS_VIDX, NT, true, LINES, BURST>(a, p, it, slab, lane);
             }
             if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), step + 1u);
         }
@@ -691,6 +712,11 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
         } else {
             if (a.variant_idx) dk = nt ? gt_stream_dyn_kernel<7, true, true> : gt_stream_dyn_kernel<7, true, false>;
             else dk = nt ? gt_stream_dyn_kernel<7, false, true> : gt_stream_dyn_kernel<7, false, false>;
+            const char *ebu = getenv("PGENHIP_WIDE_BURST");
+            const int burst = ebu ? atoi(ebu) : 1;
+            if (!a.variant_idx && nt && burst == 2) dk = gt_stream_dyn_kernel<7, false, true, false, 2>;
+            if (!a.variant_idx && nt && burst == 4) dk = gt_stream_dyn_kernel<7, false, true, false, 4>;
+            if (!a.variant_idx && nt && burst == 8) dk = gt_stream_dyn_kernel<7, false, true, false, 8>;
         }
         // launch exactly what is resident (62 VGPRs -> 8 waves/SIMD -> four 512-thread blocks per CU; 25 KB of LDS
         // each): blocks beyond that would only start when the queue is already empty.  Interleaved A/B on the chr22
