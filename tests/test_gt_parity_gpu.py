@@ -399,6 +399,47 @@ def test_config3_full_size_100k_by_500k():
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("batch", ["1", "0"])
+def test_config5_geometry_100k_by_500k_keep_1pct(monkeypatch, batch):
+    """BASELINE config 5's per-GPU geometry in ONE launch: 100 000 variants x 500 000 samples
+    (12.5 GB of records, offsets beyond 2^32), the 1 % splitmix keep mask of SURVEY 8(d)
+    (4 940 kept -> 19 761-byte rows, 1.98 GB of text).  Gather kernel (batch=1) and per-row scan
+    kernel (batch=0): LF / TAB / slash columns over the whole buffer, byte equality with the
+    oracle on rows from the start, the reference's u32-wrap boundary, the middle and the end,
+    and equality of the two kernels' whole outputs through a checksum of checksums."""
+    monkeypatch.setenv("PGENHIP_SCAN_BATCH", batch)
+    n, v = 500_000, 100_000
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < v * 125_000 + (8 << 30):
+        pytest.skip("needs ~21 GiB of free HBM")
+    kept = oracle.synth_keep(n, modulus=100)
+    k = int(kept.size)
+    row = 4 * k + 1
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        recs = eng.synth_records(v)
+        out = eng.decode_emit(recs, v, kernel=_capi.KERNEL_SCAN)
+        eng.wait()
+        assert out.numel() == v * row
+        assert bool((out[row - 1 :: row] == 10).all())
+        body = out.view(v, row)[:, :-1].reshape(v, k, 4)
+        assert bool((body[:, :, 0] == 9).all()) and bool((body[:, :, 2] == 47).all())
+        for j in (0, 1, 34_359, 34_360, 34_361, 50_000, 77_777, 99_998, 99_999):
+            got = out[j * row : (j + 1) * row].cpu().numpy()
+            host = oracle.synth_records(n, 1, first_variant=j)
+            assert got.tobytes() == oracle.decode_emit(host, 1, n, kept_idx=kept).tobytes(), f"row {j}"
+        # checksum of per-row checksums (int64 sums of the bytes weighted by column): equal for both kernels
+        w = torch.arange(1, row + 1, dtype=torch.int64, device=DEV)
+        sums = (out.view(v, row).to(torch.int64) * w).sum(dim=1)
+        digest = int((sums * torch.arange(1, v + 1, dtype=torch.int64, device=DEV)).sum().item())
+        del body, out, recs, sums
+    torch.cuda.empty_cache()
+    seen = _CONFIG5_DIGEST.setdefault("digest", digest)
+    assert seen == digest, "gather and per-row scan kernels disagree somewhere in the 1.98 GB of text"
+
+
+_CONFIG5_DIGEST = {}
+
+
 @pytest.mark.parametrize("stream,dyn", [(7, 1), (7, 0), (3, 0), (0, 0)])
 def test_wide_kernel_many_steps_ring_reuse(monkeypatch, stream, dyn):
     """Enough items per block that the loader/storer LDS ring is reused many times and the work queue
