@@ -27,6 +27,7 @@ struct pgenhip_ctx {
     uint64_t *d_keep_words = nullptr;  // scan kernel: keep bitmap, zero-padded to whole segments
     uint32_t *d_seg_rank = nullptr;    // scan kernel: kept samples before each segment
     uint32_t max_seg_count = 0;        // scan kernel: most kept samples in one segment
+    uint32_t max_super_count = 0;      // scan kernel: most kept samples in an aligned triple of segments
     uint64_t *d_work = nullptr;        // stream kernel: per-XCD work-queue heads (8 x 128 B)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -187,6 +188,8 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
                 ctx->max_seg_count = std::max(ctx->max_seg_count, seg_rank[g + 1u]);
                 seg_rank[g + 1u] += seg_rank[g];
             }
+            for (uint32_t g = 0; g < n_seg_eff; g += 3u)
+                ctx->max_super_count = std::max(ctx->max_super_count, seg_rank[std::min(g + 3u, n_seg_eff)] - seg_rank[g]);
             if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_keep_words), words.size() * sizeof(uint64_t))) != hipSuccess) { rc = fail_hip(e, "hipMalloc(keep bitmap)"); break; }
             if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_seg_rank), seg_rank.size() * sizeof(uint32_t))) != hipSuccess) { rc = fail_hip(e, "hipMalloc(segment ranks)"); break; }
             if ((e = hipMemcpy(ctx->d_keep_words, words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(keep bitmap)"); break; }
@@ -287,7 +290,7 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
                 if (very_sparse || ctx->record_size < 16u) {
                     HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
                 } else {
-                    ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count};
+                    ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
                     HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
                 }
             } else if (gt_span_applicable(a) && getenv("PGENHIP_USE_SPAN"))
@@ -308,7 +311,7 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
         case PGENHIP_KERNEL_SCAN: {
             if (!ctx->subset) return fail(PGENHIP_ERR_BAD_ARG, "scan kernel needs a kept-sample list");
             if (ctx->record_size < 16u) return fail(PGENHIP_ERR_BAD_ARG, "scan kernel needs N >= 61 (records of >= 16 bytes)");
-            ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count};
+            ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
             HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         }

@@ -481,6 +481,161 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather_kernel(EmitArgs a, Sc
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gt_scan_gather3_kernel — gt_scan_gather_kernel with a block owning THREE consecutive segments
+// (49 152 samples, 12 KiB of every record).  Measured on the config-5 geometry, the 2 GB of text
+// cost as much as 6 GB would in a stream: a row's output arrives as 31 pieces of ~656 bytes from 31
+// different blocks at different times, every piece with two partly written 128-B lines.  Here a
+// wave writes a row's three pieces as ONE run (three times fewer, three times longer pieces), and
+// the register rotation needs no unrolled row loop: buffer q always holds sub-segment q and is
+// re-loaded with the NEXT row's sub-segment q as soon as it has been parked (prefetch distance =
+// one row piece).  The rank -> sample table comes straight from the kept list the context already
+// holds (ascending u32 indices, src/pfile.rs:319-333), so no bitmap is staged at all.
+// Launch precondition: at most kGatherMaxSegCodes kept samples in any aligned triple of segments.
+constexpr uint32_t kSubSegs = 3;
+constexpr uint32_t kSuperSamples = kSubSegs * kSegSamples;
+
+template <bool HAS_VIDX>
+__global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t n_super, uint32_t row_groups)
+{
+    __shared__ uint16_t s_idx[kGatherMaxSegCodes + 2];                // rank -> sample index inside the block's 49 152 samples
+    __shared__ uint32_t s_live;                                       // bit t: tile t (of 12) holds a kept sample
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kWaves][kGatherRing];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ss = blockIdx.x % n_super;
+    const uint32_t row_group = blockIdx.x / n_super;
+
+    // kept samples before each of the block's sub-segment boundaries (global ranks)
+    uint32_t kq[kSubSegs + 1];
+#pragma unroll
+    for (uint32_t q = 0; q <= kSubSegs; q++) kq[q] = __builtin_amdgcn_readfirstlane(sc.seg_rank[min(ss * kSubSegs + q, n_seg)]);
+    const uint32_t K = a.kept_count;
+    const uint32_t seg_k0 = kq[0];
+    const uint32_t seg_cnt = kq[kSubSegs] - kq[0];
+    const bool last_seg = ss + 1u == n_super;
+    const uint32_t R = a.record_size;
+    const uint64_t row_step = (uint64_t)row_groups * kWaves;
+    const uint64_t j0 = (uint64_t)row_group * kWaves + wave;
+    const uint64_t rows = j0 < a.n_variants ? (a.n_variants - j0 + row_step - 1ull) / row_step : 0ull;
+
+    if (seg_cnt == 0u) {
+        // nothing of these segments is kept; the last block of a row still owes the '\n' (:190)
+        if (last_seg)
+            for (uint64_t n = lane; n < rows; n += 64ull) a.out[(j0 + n * row_step) * a.out_stride + 4ull * K] = (uint8_t)'\n';
+        return;
+    }
+    if (tid == 0u) s_live = 0u;
+    __syncthreads();
+    {
+        uint32_t live = 0u;
+        for (uint32_t r = tid; r < seg_cnt; r += (uint32_t)kThreads) {
+            const uint32_t idx = a.kept_idx[seg_k0 + r] - ss * kSuperSamples;  // < 49 152
+            s_idx[r] = (uint16_t)idx;
+            live |= 1u << (idx / kTileSamples);
+        }
+        if (live != 0u) atomicOr(&s_live, live);
+    }
+    __syncthreads();
+    if (rows == 0ull) return;
+    const uint32_t live_tiles = __builtin_amdgcn_readfirstlane(s_live);
+
+    uint8_t *const ring = s_ring[wave];
+    uint8_t *const stage = s_stage[wave];
+    // Loads: a tile that lies wholly inside the record is read at scalar base + lane offset + immediate (no
+    // per-tile address registers); the ONE record tile that holds the record's last byte, and tiles behind
+    // it, read a window pulled back into the record (R >= 16), shifted into place when it is parked.
+    const uint32_t tail_t = (R - 1u) >> 10;                                  // record tile holding the last record byte
+    const uint32_t tail_b = tail_t * 1024u + lane * 16u;
+    const uint32_t tail_off = min(tail_b, R - 16u);                          // pulled-back window of this lane
+    const uint32_t tail_shift = tail_b + 16u <= R ? 0u : min(tail_b - (R - 16u), 16u);
+    auto load_sub = [&](uint64_t n, uint32_t q, v4u(&dst)[kTilesPerSeg]) {
+        const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
+        const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
+        const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
+        const uint32_t tile0 = (ss * kSubSegs + q) * kTilesPerSeg;          // first record tile of the sub-segment
+        const uint8_t *__restrict__ sub = rec + (uint64_t)tile0 * 1024u;    // scalar; tiles add an immediate
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) {
+            if (tile0 + t < tail_t)
+                __builtin_memcpy(&dst[t], sub + lane * 16u + t * 1024u, 16);
+            else
+                __builtin_memcpy(&dst[t], rec + tail_off, 16);
+        }
+    };
+    uint32_t base = 0u;  // ring position of rank 0 (of this block's ranks) of the row being scanned
+    auto scan_sub = [&](const v4u(&w)[kTilesPerSeg], uint32_t q) {
+        const uint32_t r0 = kq[q] - kq[0], r1 = kq[q + 1u] - kq[0];
+        if (r0 == r1) return;  // no kept sample in this sub-segment
+#pragma unroll
+        for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
+            if (!(live_tiles & (1u << (q * kTilesPerSeg + tile)))) continue;
+            v4u x = w[tile];
+            if ((ss * kSubSegs + q) * kTilesPerSeg + tile == tail_t) {  // the record's last tile: windows were pulled back
+                uint64_t lo, hi;
+                window_halves(x, tail_shift, lo, hi);
+                x = v4u{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+            }
+            *reinterpret_cast<v4u *>(stage + tile * 1024u + lane * 16u) = x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lane r takes kept sample r (src/pfile.rs:171-175): byte idx / 4, bits 2 * (idx % 4)
+#pragma unroll 2
+        for (uint32_t r = r0 + lane; r < r1; r += 64u) {
+            const uint32_t idx = (uint32_t)s_idx[r] - q * kSegSamples;
+            const uint32_t byte = stage[idx >> 2];
+            ring[(base + r) & (kGatherRing - 1u)] = (uint8_t)((byte >> ((idx & 3u) * 2u)) & 3u);
+        }
+        // the stage is rewritten by the next sub-segment: its reads above must have returned first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto landed = [&](const v4u(&w)[kTilesPerSeg]) {
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) asm volatile("" ::"v"(w[t].x), "v"(w[t].y), "v"(w[t].z), "v"(w[t].w));
+    };
+
+    const uint32_t fit = (kGatherRing - 8u) / seg_cnt - 1u;              // >= 3 by the launch precondition
+    const uint64_t batch = (uint64_t)min(fit, kGatherMaxRows);
+    v4u b0[kTilesPerSeg], b1[kTilesPerSeg], b2[kTilesPerSeg];
+    load_sub(0ull, 0u, b0);
+    load_sub(0ull, 1u, b1);
+    load_sub(0ull, 2u, b2);
+    uint64_t n = 0ull;       // rows scanned
+    uint64_t flushed = 0ull; // rows written
+    while (n < rows) {
+        const uint64_t batch_end = min(rows, n + batch);
+        // ---- scan: loads and LDS only
+        do {
+            landed(b0);
+            scan_sub(b0, 0u);
+            load_sub(n + 1ull, 0u, b0);
+            landed(b1);
+            scan_sub(b1, 1u);
+            load_sub(n + 1ull, 1u, b1);
+            landed(b2);
+            scan_sub(b2, 2u);
+            load_sub(n + 1ull, 2u, b2);
+            base += seg_cnt;
+        } while (++n < batch_end);
+        // ---- flush the batch: one run of text per row
+#pragma nounroll
+        for (; flushed < n; flushed++) {
+            uint8_t *const row_out = a.out + (j0 + flushed * row_step) * a.out_stride;
+            const uint64_t lo_emit = 4ull * seg_k0;
+            const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
+            flush_range<kGatherRing>(ring, (uint32_t)flushed * seg_cnt, row_out, lo_emit, hi_emit, seg_k0, K, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 // Every block walks the same number of rows, so the launch must be exactly ONE resident round: a grid
@@ -500,12 +655,25 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hi
     if (a.n_variants == 0) return hipSuccess;
     const uint32_t n_seg = (a.sample_count + kSegSamples - 1u) / kSegSamples;
     const uint32_t n_seg_eff = n_seg ? n_seg : 1u;
-    // gather kernel whenever every segment's kept codes fit its ring four times over (sparse keeps: <= 6 % of a
-    // segment); PGENHIP_SCAN_BATCH=0 forces the per-row kernel (A/B)
+    // gather kernels whenever the kept codes of a block's samples fit its ring four times over (sparse keeps:
+    // <= 6 % of a segment, <= 2 % of a segment triple); PGENHIP_SCAN_BATCH=0 forces the per-row kernel and
+    // PGENHIP_SCAN_SUPER=0 the one-segment gather kernel (A/B)
     const char *es = getenv("PGENHIP_SCAN_BATCH");
-    const bool batch_ok = sc.max_seg_count <= kGatherMaxSegCodes;
-    const bool batch_kernel = batch_ok && (es ? atoi(es) != 0 : true);
+    const char *eu = getenv("PGENHIP_SCAN_SUPER");
+    const bool batch_on = es ? atoi(es) != 0 : true;
+    const bool super_kernel = batch_on && a.kept_idx != nullptr && sc.max_super_count <= kGatherMaxSegCodes && (eu ? atoi(eu) != 0 : true);
+    const bool batch_kernel = batch_on && !super_kernel && sc.max_seg_count <= kGatherMaxSegCodes;
     const bool dense = (uint64_t)a.kept_count * 4ull > (uint64_t)a.sample_count * 3ull;  // > 75 % kept
+    const uint64_t groups_needed = ((uint64_t)a.n_variants + kWaves - 1ull) / kWaves;
+    if (super_kernel) {
+        void (*k3)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t) = a.variant_idx ? gt_scan_gather3_kernel<true> : gt_scan_gather3_kernel<false>;
+        const uint32_t n_super = (n_seg_eff + kSubSegs - 1u) / kSubSegs;
+        uint64_t groups = (uint64_t)resident_blocks(k3, kThreads, num_cus) / n_super;
+        if (groups < 1ull) groups = 1ull;
+        if (groups > groups_needed) groups = groups_needed;
+        hipLaunchKernelGGL(k3, dim3((uint32_t)(groups * n_super)), dim3(kThreads), 0, stream, a, sc, n_seg_eff, n_super, (uint32_t)groups);
+        return hipGetLastError();
+    }
     void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t);
     if (batch_kernel)
         kern = a.variant_idx ? gt_scan_gather_kernel<true> : gt_scan_gather_kernel<false>;
@@ -513,7 +681,6 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hi
         kern = dense ? gt_scan_kernel<true, true> : gt_scan_kernel<true, false>;
     else
         kern = dense ? gt_scan_kernel<false, true> : gt_scan_kernel<false, false>;
-    const uint64_t groups_needed = ((uint64_t)a.n_variants + kWaves - 1ull) / kWaves;
     uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus) / n_seg_eff;  // floor: never a partial second round
     if (groups < 1ull) groups = 1ull;  // more segments than resident blocks (N > ~16 M samples): rounds are unavoidable
     if (groups > groups_needed) groups = groups_needed;
