@@ -560,10 +560,8 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
         const uint8_t *__restrict__ sub = rec + (uint64_t)tile0 * 1024u;    // scalar; tiles add an immediate
 #pragma unroll
         for (uint32_t t = 0; t < kTilesPerSeg; t++) {
-            if (tile0 + t < tail_t)
-                __builtin_memcpy(&dst[t], sub + lane * 16u + t * 1024u, 16);
-            else
-                __builtin_memcpy(&dst[t], rec + tail_off, 16);
+            const uint8_t *src16 = tile0 + t < tail_t ? sub + lane * 16u + t * 1024u : rec + tail_off;
+            __builtin_memcpy(&dst[t], src16, 16);  // (streaming `nt` loads were measured: 3.3-3.5 ms instead of 2.9-3.0)
         }
     };
     uint32_t base = 0u;  // ring position of rank 0 (of this block's ranks) of the row being scanned
