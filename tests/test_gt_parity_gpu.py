@@ -219,6 +219,23 @@ def test_scan_kernels_many_rows_per_wave(monkeypatch, batch):
             assert (got == exp).all(), f"mask {label} v={v} batch={batch}"
 
 
+@pytest.mark.parametrize("n", [16384, 16385, 49152, 49153, 70001, 98304, 100003, 147457])
+def test_sparse_subsets_segment_triples(n):
+    """Sparse keeps where the number of 16 384-sample segments is 1..10, i.e. the last block of the
+    three-segment gather kernel owns one, two or three segments and the record ends in any of its
+    tiles; kept samples include the very first and the very last sample."""
+    rng = np.random.default_rng(900 + n)
+    v = 41
+    r = oracle.variant_record_size(n)
+    recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
+    kept = np.unique(np.concatenate([[0, n - 1], rng.choice(n, size=max(2, n // 150), replace=False)])).astype(np.uint32)
+    want = oracle.decode_emit(recs, v, n, kept_idx=kept).reshape(v, -1)
+    for kern in (_capi.KERNEL_AUTO, _capi.KERNEL_SCAN):
+        got, k = run_engine(recs, v, n, kept=kept, kernel=kern)
+        exp = expect_buffer(want, v, k, 4 * k + 1, 0, got.size)
+        assert (got == exp).all(), f"n={n} kernel {kern}"
+
+
 def test_single_variant_and_zero_variants():
     n = 90
     recs = np.arange(oracle.variant_record_size(n), dtype=np.uint8)
