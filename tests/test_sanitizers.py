@@ -53,3 +53,31 @@ def test_host_code_under_asan_ubsan(asan_cli, tmp_path):
         p = subprocess.run([str(asan_cli), *args], capture_output=True, env=env)
         assert p.returncode == 101, p.stderr.decode()[-2000:]
         assert b"AddressSanitizer" not in p.stderr and b"runtime error" not in p.stderr
+
+
+def test_parallel_metadata_filter_under_asan_and_tsan(asan_cli, tmp_path):
+    """N2's threaded pvar walk (forced to 4 pieces on the small basic1 file): same answer as the
+    serial walk under ASan+UBSan, and no data race reports from a ThreadSanitizer build."""
+    for ext in ("pvar", "psam"):
+        shutil.copy(GOLDEN / "basic1" / f"basic1.{ext}", tmp_path / f"basic1.{ext}")
+    n, v = 2504, 17784
+    (tmp_path / "basic1.pgen").write_bytes(bytes([0x6C, 0x1B, 0x02]) + v.to_bytes(4, "little") + n.to_bytes(4, "little") + b"\x40")
+    args = ["filter", str(tmp_path / "basic1"), "--include-var", 'ALT=="G"', "--dry-run", "-o", str(tmp_path / "h.vcf")]
+    outs = []
+    for threads in ("1", "4"):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", PGENHIP_FILTER_THREADS=threads)
+        p = subprocess.run([str(asan_cli), *args], capture_output=True, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        outs.append(p.stdout)
+    assert outs[0] == outs[1] and b'"variants_kept": 4130' in outs[0]
+
+    tsan = tmp_path / "pgen-hip-tsan"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-I", str(REPO / "include"), "-o", str(tsan),
+           *[str(HOST / f) for f in ("cli.cpp", "pfile.cpp", "csvlite.cpp", "expr.cpp")],
+           "-L", str(REPO / "pgen_rs_amd"), "-lpgen_hip", f"-Wl,-rpath,{REPO / 'pgen_rs_amd'}"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    env = dict(os.environ, PGENHIP_FILTER_THREADS="4", TSAN_OPTIONS="halt_on_error=1")
+    p = subprocess.run([str(tsan), *args], capture_output=True, env=env)
+    assert p.returncode == 0 and p.stdout == outs[0], p.stderr.decode()[-3000:]
+    assert b"ThreadSanitizer" not in p.stderr
