@@ -659,7 +659,8 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hi
     const char *es = getenv("PGENHIP_SCAN_BATCH");
     const char *eu = getenv("PGENHIP_SCAN_SUPER");
     const bool batch_on = es ? atoi(es) != 0 : true;
-    const bool super_kernel = batch_on && a.kept_idx != nullptr && sc.max_super_count <= kGatherMaxSegCodes && (eu ? atoi(eu) != 0 : true);
+    // (records shorter than three segments: the one-segment kernel — a triple block would issue 12 loads per row for 4 KiB or less)
+    const bool super_kernel = batch_on && a.kept_idx != nullptr && sc.max_super_count <= kGatherMaxSegCodes && (eu ? atoi(eu) != 0 : n_seg_eff >= kSubSegs);
     const bool batch_kernel = batch_on && !super_kernel && sc.max_seg_count <= kGatherMaxSegCodes;
     const bool dense = (uint64_t)a.kept_count * 4ull > (uint64_t)a.sample_count * 3ull;  // > 75 % kept
     const uint64_t groups_needed = ((uint64_t)a.n_variants + kWaves - 1ull) / kWaves;
