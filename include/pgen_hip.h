@@ -91,6 +91,7 @@ uint64_t pgenhip_gt_row_bytes(const pgenhip_ctx *ctx);
 #define PGENHIP_KERNEL_SCAN 3u   /* kept-subset scan + wave ballot/popcount compaction */
 #define PGENHIP_KERNEL_WIDE 4u   /* dense all-samples, wide LDS-staged record loads, one row piece per item (N >= 1024) */
 #define PGENHIP_KERNEL_SPAN 5u   /* dense all-samples, 16-KiB stream spans across row ends (N >= 2048) */
+#define PGENHIP_KERNEL_PICK 6u   /* kept subset on short records (61 <= N <= 4096, K >= 4, dense pitch): output-driven pick through the kept list */
 #define PGENHIP_KERNEL_MASK 0xFu
 
 /* src/pfile.rs:165-190 for a block of n_variants kept variants.

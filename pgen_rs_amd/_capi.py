@@ -36,6 +36,7 @@ KERNEL_FLAT = 2
 KERNEL_SCAN = 3
 KERNEL_WIDE = 4
 KERNEL_SPAN = 5
+KERNEL_PICK = 6
 SYNTH_DIRTY_PAD = 1
 
 u8p = C.POINTER(C.c_uint8)

@@ -287,7 +287,10 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
                 // records the list gather touches only the kept samples' lines and wins; everywhere else the
                 // scan + LDS-compaction kernel does (it reads each record once with wide loads)
                 const bool very_sparse = ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 128ull <= ctx->sample_count;
-                if (very_sparse || ctx->record_size < 16u) {
+                if (gt_pick_applicable(a)) {
+                    // short records (the 1000 Genomes shape with a sample filter): output-driven pick, any density
+                    HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
+                } else if (very_sparse || ctx->record_size < 16u) {
                     HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
                 } else {
                     ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
@@ -315,6 +318,10 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
             HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         }
+        case PGENHIP_KERNEL_PICK:
+            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "pick kernel needs a kept-sample list with K >= 4, 61 <= N <= 4096 and out_stride == 4K+1");
+            HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
         case PGENHIP_KERNEL_SPAN:
             if (!gt_span_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "span kernel needs all samples kept, N >= 2048 and out_stride == 4N+1");
             HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream));

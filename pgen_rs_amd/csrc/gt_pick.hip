@@ -1,0 +1,237 @@
+// gt_pick.hip — kept subsets on SHORT records (N <= 4096 samples, R <= 1 KiB: the 1000 Genomes
+// shape with a sample filter), any density (gfx950 / MI355X).
+//
+// Replaces /root/reference/src/pfile.rs:165-190 when `--include-sam` is active and a record is
+// at most one 1-KiB tile.  The scan kernels of gt_scan.hip are built around 16 384-sample segments
+// and a per-row code ring; on a 626-byte record they spend a wave on one row piece at a time and
+// most of their loads on nothing.  Here everything is OUTPUT-driven and there is no compaction
+// step at all:
+//   * the kept-sample list the context already holds (ascending u32 indices, what filter_metadata
+//     src/pfile.rs:319-333 yields) is copied once per block into LDS as u16: it IS the
+//     rank -> sample table;
+//   * a wave takes BATCHES of B consecutive rows: one 16-B-per-lane load instruction per row
+//     (issued for the next batch before this batch's text goes out), the rows parked in the
+//     wave's LDS stage at a 16-B-padded pitch;
+//   * the batch's output is one contiguous run of B x (4K+1) bytes (dense pitch is a launch
+//     precondition).  Lanes own 16-byte-ALIGNED chunks of it; a chunk at run offset o lies in row
+//     i = o / (4K+1) at row byte p: its five genotypes are ranks p/4 .. p/4+4 of that row — five
+//     u16 reads of the table, five byte reads of the staged record (src/pfile.rs:171-175), the
+//     usual text dwords and funnel shift (:177-190).  A chunk that holds a row's '\n' merges the
+//     tail of row i with the head of row i+1 in registers, so it is still one 16-B store;
+//   * the run's first and last partial chunk (shared with the neighbouring waves' runs) go out as
+//     ONE byte-store instruction (lanes 0-15 head bytes, 16-31 tail bytes).
+// HBM traffic per row: the record once + 4K+1 bytes of text; the kept list once per block.
+#include "gt_common.hip.h"
+#include "kernels.h"
+
+namespace pgenhip {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr uint32_t kMaxSamples = 4096;          // R <= 1024: one 16-B piece per lane covers a record
+constexpr uint32_t kStageBytes = 8192;          // per wave: B rows at the padded pitch
+constexpr int kMaxBatchRows = 12;
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+struct PickParams {
+    uint32_t pieces;      // 16-B pieces per record = ceil(R / 16) (<= 64)
+    uint32_t pitch;       // bytes per staged row = pieces * 16
+    uint32_t batch_rows;  // B
+    uint32_t row_bytes;   // S = 4K + 1
+    uint32_t magic;       // floor(2^32 / S) + 1: o / S = umulhi(o, magic) for o < 2^20 (checked on the host), fixed up by one compare
+    uint32_t n_batches;
+};
+
+// run offset -> (row in batch, row byte)
+__device__ __forceinline__ void split_offset(uint32_t o, const PickParams &p, uint32_t &i, uint32_t &pos)
+{
+    i = __umulhi(o, p.magic);
+    if (i * p.row_bytes > o) i--;
+    pos = o - i * p.row_bytes;
+}
+
+// 2-bit code of kept sample `rank` of staged row `row` (ranks outside 0..K-1 are clamped: their bytes are never stored)
+__device__ __forceinline__ uint32_t pick_code(const uint8_t *row, const uint16_t *idx, int32_t rank, uint32_t K)
+{
+    const uint32_t r = (uint32_t)max(0, min(rank, (int32_t)K - 1));
+    const uint32_t s = idx[r];
+    return ((uint32_t)row[s >> 2] >> ((s & 3u) * 2u)) & 3u;
+}
+
+// 16 text bytes of staged row `row` starting at row byte q (q may be negative: the bytes before the row are don't-care)
+__device__ __forceinline__ u32x4 pick_text16(const uint8_t *row, const uint16_t *idx, int32_t q, uint32_t K)
+{
+    const int32_t g = q >> 2;  // floor
+    const uint32_t sh = (uint32_t)q & 3u;
+    const uint32_t t0 = gt_text(pick_code(row, idx, g, K));
+    const uint32_t t1 = gt_text(pick_code(row, idx, g + 1, K));
+    const uint32_t t2 = gt_text(pick_code(row, idx, g + 2, K));
+    const uint32_t t3 = gt_text(pick_code(row, idx, g + 3, K));
+    const uint32_t t4 = gt_text(pick_code(row, idx, g + 4, K));
+    u32x4 v;
+    v.x = funnel_bytes(t0, t1, sh);
+    v.y = funnel_bytes(t1, t2, sh);
+    v.z = funnel_bytes(t2, t3, sh);
+    v.w = funnel_bytes(t3, t4, sh);
+    return v;
+}
+
+template <bool HAS_VIDX>
+__global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParams p)
+{
+    __shared__ uint16_t s_idx[kMaxSamples];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t K = a.kept_count;
+    for (uint32_t r = tid; r < K; r += (uint32_t)kThreads) s_idx[r] = (uint16_t)a.kept_idx[r];
+    __syncthreads();
+
+    uint8_t *const stage = s_stage[wave];
+    const uint32_t R = a.record_size;
+    const uint32_t S = p.row_bytes;
+    const uint32_t B = p.batch_rows;
+    // the record's last piece is read pulled back into the record (R >= 16) and shifted into place when parked
+    const uint32_t piece_off = min(lane * 16u, R - 16u);
+    const uint32_t tail_shift = lane * 16u + 16u <= R ? 0u : min(lane * 16u - (R - 16u), 16u);
+
+    const uint32_t batch_step = gridDim.x * kWaves;
+    uint32_t bi = blockIdx.x * kWaves + wave;
+    if (bi >= p.n_batches) return;
+
+    v4u buf[kMaxBatchRows];
+    auto load_batch = [&](uint32_t b) {
+        const uint64_t row0 = (uint64_t)b * B;
+#pragma unroll
+        for (int i = 0; i < kMaxBatchRows; i++) {
+            buf[i] = v4u{0u, 0u, 0u, 0u};
+            if ((uint32_t)i < B) {
+                const uint64_t row = min(row0 + (uint64_t)i, (uint64_t)a.n_variants - 1ull);  // rows past the end re-load the last row
+                const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
+                const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
+                if (lane < p.pieces) __builtin_memcpy(&buf[i], rec + piece_off, 16);
+            }
+        }
+    };
+    load_batch(bi);
+
+    for (;;) {
+        // ---- park this batch's rows (waits for their loads — and, gfx9 having one in-order vmcnt, for the
+        // previous batch's stores: one drain per batch of >= 16 KiB of text or 12 rows)
+#pragma unroll
+        for (int i = 0; i < kMaxBatchRows; i++) {
+            if ((uint32_t)i < B && lane < p.pieces) {
+                v4u x = buf[i];
+                if (tail_shift != 0u) {
+                    uint64_t lo = (uint64_t)x.x | ((uint64_t)x.y << 32), hi = (uint64_t)x.z | ((uint64_t)x.w << 32);
+                    const uint32_t sh8 = tail_shift * 8u;  // < 128: a lane with a whole piece outside the record does not exist (lane < pieces)
+                    if (sh8 >= 64u) { lo = hi >> (sh8 - 64u); hi = 0ull; }
+                    else { lo = (lo >> sh8) | (hi << (64u - sh8)); hi >>= sh8; }
+                    x = v4u{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+                }
+                *reinterpret_cast<v4u *>(stage + (uint32_t)i * p.pitch + lane * 16u) = x;
+            }
+        }
+        const uint32_t bi_next = bi + batch_step;
+        const bool more = bi_next < p.n_batches;
+        if (more) load_batch(bi_next);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- emit: one contiguous run of rows_here x S bytes
+        const uint64_t row0 = (uint64_t)bi * B;
+        const uint32_t rows_here = (uint32_t)min((uint64_t)B, (uint64_t)a.n_variants - row0);
+        const uint32_t len = rows_here * S;
+        uint8_t *const run = a.out + row0 * (uint64_t)S;
+        const uint32_t mis = (uint32_t)(uintptr_t)run & 15u;
+        const uint32_t head = min((16u - mis) & 15u, len);     // bytes before the first whole chunk
+        const uint32_t n_chunks = (len - head) >> 4;
+        const uint32_t tail_off = head + (n_chunks << 4);
+        const uint32_t tail = len - tail_off;                   // bytes after the last whole chunk (< 16)
+        for (uint32_t c = lane; c < n_chunks; c += 64u) {
+            const uint32_t o = head + (c << 4);
+            uint32_t i, pos;
+            split_offset(o, p, i, pos);
+            const uint8_t *row = stage + i * p.pitch;
+            u32x4 v = pick_text16(row, s_idx, (int32_t)pos, K);
+            const uint32_t nl = S - 1u - pos;                   // chunk byte of this row's '\n' if < 16
+            if (nl < 16u) {
+                // the chunk holds '\n' at byte nl and the head of the next row behind it (a whole chunk never ends the run)
+                u32x4 y = {0u, 0u, 0u, 0u};
+                if (nl < 15u) y = pick_text16(row + p.pitch, s_idx, -(int32_t)nl - 1, K);
+                uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+                uint32_t ys[4] = {y.x, y.y, y.z, y.w};
+                uint32_t os[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int32_t nb = (int32_t)nl - 4 * m;     // bytes of dword m taken from this row
+                    const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+                    uint32_t d = (xs[m] & mask) | (ys[m] & ~mask);
+                    if (nb >= 0 && nb < 4) d = (d & ~(0xFFu << (8 * nb))) | (0x0Au << (8 * nb));
+                    os[m] = d;
+                }
+                v = u32x4{os[0], os[1], os[2], os[3]};
+            }
+            v4u t = {v.x, v.y, v.z, v.w};
+            *reinterpret_cast<v4u *>(run + o) = t;
+        }
+        {
+            // edge bytes of the run: lanes 0-15 the head, lanes 16-31 the tail
+            const uint32_t o = lane < 16u ? lane : tail_off + (lane - 16u);
+            const bool on = lane < 16u ? lane < head : (lane < 32u && lane - 16u < tail);
+            if (on) {
+                uint32_t i, pos;
+                split_offset(o, p, i, pos);
+                const uint32_t code = pick_code(stage + i * p.pitch, s_idx, (int32_t)(pos >> 2), K);
+                run[o] = (uint8_t)(pos == S - 1u ? 0x0Au : gt_text_byte(code, pos & 3u));
+            }
+        }
+        if (!more) break;
+        // the stage is rewritten by the next batch: this batch's reads must have returned first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bi = bi_next;
+    }
+}
+
+}  // namespace
+
+bool gt_pick_applicable(const EmitArgs &a)
+{
+    // kept subset, record of one tile (16 <= R <= 1024), rows of >= 17 bytes (a 16-B chunk then touches at most two
+    // rows), dense output pitch, no full-line mode
+    return a.kept_idx != nullptr && a.line_off == nullptr && a.sample_count <= kMaxSamples && a.record_size >= 16u &&
+           a.kept_count >= 4u && (a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull);
+}
+
+hipError_t launch_gt_pick(const EmitArgs &a, int num_cus, hipStream_t stream)
+{
+    if (a.n_variants == 0) return hipSuccess;
+    PickParams p;
+    p.pieces = (a.record_size + 15u) / 16u;
+    p.pitch = p.pieces * 16u;
+    p.row_bytes = 4u * a.kept_count + 1u;
+    // rows per batch: ~16 KiB of text per batch, what the stage holds, what the register buffer holds
+    uint32_t b = (16384u + p.row_bytes - 1u) / p.row_bytes;
+    b = b < 1u ? 1u : b;
+    if (b > (uint32_t)kMaxBatchRows) b = (uint32_t)kMaxBatchRows;
+    if (b > kStageBytes / p.pitch) b = kStageBytes / p.pitch;  // >= 8 (pitch <= 1024)
+    p.batch_rows = b;
+    p.magic = (uint32_t)(0x100000000ull / p.row_bytes) + 1u;    // exact up to one compare for run offsets < 12 * 16 385 < 2^20
+    p.n_batches = (uint32_t)(((uint64_t)a.n_variants + b - 1u) / b);
+    void (*kern)(EmitArgs, PickParams) = a.variant_idx ? gt_pick_kernel<true> : gt_pick_kernel<false>;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const uint64_t need = ((uint64_t)p.n_batches + kWaves - 1ull) / kWaves;
+    const uint64_t cap = (uint64_t)per_cu * (uint64_t)num_cus;
+    hipLaunchKernelGGL(kern, dim3((uint32_t)(need < cap ? need : cap)), dim3(kThreads), 0, stream, a, p);
+    return hipGetLastError();
+}
+
+}  // namespace pgenhip

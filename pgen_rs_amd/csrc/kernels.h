@@ -55,6 +55,10 @@ struct ScanArgs {
 };
 hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hipStream_t stream);
 
+// kept subsets on short records (N <= 4096): output-driven pick through the kept list, no compaction (gt_pick.hip)
+bool gt_pick_applicable(const EmitArgs &a);
+hipError_t launch_gt_pick(const EmitArgs &a, int num_cus, hipStream_t stream);
+
 // Deterministic synthetic records (SURVEY.md §8d counter-based generator).
 hipError_t launch_synth_records(uint8_t *dst, uint64_t record_stride, uint32_t sample_count,
                                 uint64_t first_variant, uint32_t n_variants, uint64_t seed,

@@ -22,7 +22,7 @@ DEV = "cuda:0"
 SENTINEL = 0xA5
 
 
-def kernels_for(subset: bool, dense: bool, n: int = 0):
+def kernels_for(subset: bool, dense: bool, n: int = 0, k: int = 0):
     ks = [_capi.KERNEL_AUTO, _capi.KERNEL_ROWS]
     if not subset and dense and n >= 8:
         ks.append(_capi.KERNEL_FLAT)
@@ -32,6 +32,8 @@ def kernels_for(subset: bool, dense: bool, n: int = 0):
         ks.append(_capi.KERNEL_SPAN)
     if subset and n >= 61:  # the scan kernel needs records of >= 16 bytes
         ks.append(_capi.KERNEL_SCAN)
+    if subset and dense and 61 <= n <= 4096 and k >= 4:
+        ks.append(_capi.KERNEL_PICK)
     return ks
 
 
@@ -162,7 +164,7 @@ def test_kept_subsets_vs_oracle(n):
     recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
     for label, kept in keep_lists(n, rng):
         want = oracle.decode_emit(recs, v, n, kept_idx=kept).reshape(v, -1)
-        for kern in kernels_for(True, True, n):
+        for kern in kernels_for(True, True, n, int(kept.size)):
             got, k = run_engine(recs, v, n, kept=kept, kernel=kern)
             assert k == kept.size
             exp = expect_buffer(want, v, k, 4 * k + 1, 0, got.size)
@@ -234,6 +236,37 @@ def test_sparse_subsets_segment_triples(n):
         got, k = run_engine(recs, v, n, kept=kept, kernel=kern)
         exp = expect_buffer(want, v, k, 4 * k + 1, 0, got.size)
         assert (got == exp).all(), f"n={n} kernel {kern}"
+
+
+@pytest.mark.parametrize("n", [61, 64, 100, 257, 1000, 2504, 4093, 4096])
+def test_pick_kernel_short_records(n):
+    """Short-record subset kernel (N <= 4096): K from 4 to N-1 (rows of 17 bytes up), batches that
+    end mid-way (V not a multiple of the batch), unaligned output pointers (the run's head and tail
+    edges), a gapped variant list and a padded record stride; sentinel bytes stay untouched."""
+    rng = np.random.default_rng(1200 + n)
+    r = oracle.variant_record_size(n)
+    masks = {
+        "k4": np.sort(rng.choice(n, size=4, replace=False)),
+        "k5_ends": np.unique(np.concatenate([[0, n - 1], rng.choice(n, size=3, replace=False)])),
+        "1pct": np.sort(rng.choice(n, size=max(4, n // 100), replace=False)),
+        "half": np.sort(rng.choice(n, size=n // 2, replace=False)),
+        "all_but_one": np.setdiff1d(np.arange(n), [n // 3]),
+    }
+    for label, kept in masks.items():
+        kept = kept.astype(np.uint32)
+        for v, out_offset, gapped in ((1, 0, False), (7, 3, False), (1031, 0, False), (397, 9, True)):
+            v_file = v * 2 if gapped else v
+            rstride = r + 5 if gapped else r
+            recs = rng.integers(0, 256, size=v_file * rstride + 3, dtype=np.uint8)
+            vidx = np.sort(rng.choice(v_file, size=v, replace=False)) if gapped else None
+            dense = np.concatenate([recs[3 + i * rstride : 3 + i * rstride + r] for i in range(v_file)])
+            want = oracle.decode_emit(dense, v, n, kept_idx=kept, variant_idx=vidx).reshape(v, -1)
+            got, k = run_engine(recs, v, n, kept=kept, kernel=_capi.KERNEL_PICK, record_stride=rstride, variant_idx=vidx,
+                                out_offset=out_offset, records_offset=3)
+            exp = expect_buffer(want, v, k, 4 * k + 1, out_offset, got.size)
+            if not (got == exp).all():
+                bad = np.flatnonzero(got != exp)
+                raise AssertionError(f"n={n} mask={label} v={v} off={out_offset}: {bad.size} bytes differ, first at {bad[:6]}")
 
 
 def test_single_variant_and_zero_variants():
