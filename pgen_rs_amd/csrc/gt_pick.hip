@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
 
     for (;;) {
         // ---- park this batch's rows (waits for their loads — and, gfx9 having one in-order vmcnt, for the
-        // previous batch's stores: one drain per batch of >= 16 KiB of text or 12 rows)
+        // previous batch's stores: one drain per batch of ~32 KiB of text or 12 rows)
 #pragma unroll
         for (int i = 0; i < kMaxBatchRows; i++) {
             if ((uint32_t)i < B && lane < p.pieces) {
@@ -217,8 +217,11 @@ hipError_t launch_gt_pick(const EmitArgs &a, int num_cus, hipStream_t stream)
     p.pieces = (a.record_size + 15u) / 16u;
     p.pitch = p.pieces * 16u;
     p.row_bytes = 4u * a.kept_count + 1u;
-    // rows per batch: ~16 KiB of text per batch, what the stage holds, what the register buffer holds
-    uint32_t b = (16384u + p.row_bytes - 1u) / p.row_bytes;
+    // rows per batch: ~32 KiB of text per batch (8 / 16 / 32 / 64 KiB at 50 % kept on the chr22 shape: 1.44 / 1.41 / 1.37 / 1.36 ms),
+    // what the stage holds, what the register buffer holds
+    const char *eb = getenv("PGENHIP_PICK_BATCH_BYTES");  // A/B: text per batch (one store drain per batch)
+    const uint32_t batch_bytes = eb && atoi(eb) > 0 ? (uint32_t)atoi(eb) : 32768u;
+    uint32_t b = (batch_bytes + p.row_bytes - 1u) / p.row_bytes;
     b = b < 1u ? 1u : b;
     if (b > (uint32_t)kMaxBatchRows) b = (uint32_t)kMaxBatchRows;
     if (b > kStageBytes / p.pitch) b = kStageBytes / p.pitch;  // >= 8 (pitch <= 1024)
