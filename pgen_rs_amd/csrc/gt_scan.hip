@@ -113,8 +113,9 @@ __device__ __forceinline__ void window_halves(const v4u &w, uint32_t tail_shift,
 // chunk (segment / row edges, shared with the neighbouring segment's block) go out as ONE
 // byte-store instruction: lanes 0-15 take the head bytes, lanes 16-31 the tail bytes.
 // All 64-bit arithmetic is wave-uniform (scalar unit); a lane only adds a 32-bit offset.
-template <uint32_t RING = kRing>
-__device__ __forceinline__ void flush_range(const uint8_t *ring, uint32_t ring_base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
+// `code_of(x)` yields the 2-bit code at position x = base + segment rank (ring position, or rank for the pick kernel).
+template <typename CodeFn>
+__device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
                                             uint32_t seg_k0, uint32_t K, uint32_t lane)
 {
     uint8_t *const out0 = row_out + emitted;                           // first byte of the flush
@@ -124,7 +125,7 @@ __device__ __forceinline__ void flush_range(const uint8_t *ring, uint32_t ring_b
     const uint32_t n_chunks = (len - head) >> 4;
     const uint32_t tail_off = head + (n_chunks << 4);
     const uint32_t tail = len - tail_off;                              // bytes after the last whole chunk (< 16)
-    const uint32_t e4 = ring_base + (uint32_t)(emitted >> 2) - seg_k0; // ring position of the code under byte `emitted`
+    const uint32_t e4 = base + (uint32_t)(emitted >> 2) - seg_k0;      // position of the code under byte `emitted`
     const uint32_t em = (uint32_t)emitted & 3u;
     const uint64_t nl64 = 4ull * K - emitted;                          // flush offset of the row's '\n' (row byte 4K)
     const uint32_t nl = nl64 < (uint64_t)len ? (uint32_t)nl64 : 0xFFFFFFFFu;
@@ -133,11 +134,11 @@ __device__ __forceinline__ void flush_range(const uint8_t *ring, uint32_t ring_b
         const uint32_t x = em + off;                                   // byte offset from the dword boundary under `emitted`
         const uint32_t rel = e4 + (x >> 2);
         const uint32_t sh = x & 3u;
-        const uint32_t t0 = gt_text(ring_code<RING>(ring, rel));
-        const uint32_t t1 = gt_text(ring_code<RING>(ring, rel + 1u));
-        const uint32_t t2 = gt_text(ring_code<RING>(ring, rel + 2u));
-        const uint32_t t3 = gt_text(ring_code<RING>(ring, rel + 3u));
-        const uint32_t t4 = gt_text(ring_code<RING>(ring, rel + 4u));  // may be past the flush: then it feeds no byte (sh = 0) or only '\n''s place
+        const uint32_t t0 = gt_text(code_of(rel));
+        const uint32_t t1 = gt_text(code_of(rel + 1u));
+        const uint32_t t2 = gt_text(code_of(rel + 2u));
+        const uint32_t t3 = gt_text(code_of(rel + 3u));
+        const uint32_t t4 = gt_text(code_of(rel + 4u));  // may be past the flush: then it feeds no byte (sh = 0) or only '\n''s place
         v4u v = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
         // the row's '\n' can only be a whole chunk's last byte (hi_emit <= 4K + 1)
         if (off + 15u == nl) v.w = (v.w & 0x00FFFFFFu) | 0x0A000000u;
@@ -147,9 +148,16 @@ __device__ __forceinline__ void flush_range(const uint8_t *ring, uint32_t ring_b
     const bool on = lane < 16u ? lane < head : (lane < 32u && lane - 16u < tail);
     if (on) {
         const uint32_t x = em + off;
-        const uint32_t code = ring_code<RING>(ring, e4 + (x >> 2));
+        const uint32_t code = code_of(e4 + (x >> 2));
         out0[off] = (uint8_t)(off == nl ? 0x0Au : gt_text_byte(code, x & 3u));
     }
+}
+
+template <uint32_t RING = kRing>
+__device__ __forceinline__ void flush_range(const uint8_t *ring, uint32_t ring_base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
+                                            uint32_t seg_k0, uint32_t K, uint32_t lane)
+{
+    flush_codes([ring](uint32_t x) { return ring_code<RING>(ring, x); }, ring_base, row_out, emitted, hi_emit, seg_k0, K, lane);
 }
 
 // Stage a segment's keep words and their exclusive popcount prefix (once per block; needs all of
@@ -634,6 +642,115 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gt_scan_pick_kernel — kept subsets of MEDIUM density on long records (more kept samples per
+// segment than the gather kernels' rings take, at most 75 % kept).  The per-lane ctz compaction of
+// gt_scan_kernel costs 150-300 VALU instructions per store step there; this kernel has no
+// compaction at all (the idea of gt_pick.hip, per segment): the block's slice of the context's
+// kept list, as u16 offsets into the segment, IS the rank -> sample table in LDS; a wave parks a
+// row's 4 KiB of record bytes in its LDS stage and the output-driven flush (flush_codes) picks
+// every genotype straight from there: one table read + one staged-byte read per genotype.
+// A row piece is >= 4 KiB of text here, so the one store drain per row piece is amortised.
+constexpr uint32_t kPickMaxSegCodes = kSegSamples * 3u / 4u;   // 12 288 table entries = 24 KiB of LDS
+
+template <bool HAS_VIDX>
+__global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups)
+{
+    __shared__ uint16_t s_idx[kPickMaxSegCodes + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t seg = blockIdx.x % n_seg;
+    const uint32_t row_group = blockIdx.x / n_seg;
+    const uint32_t K = a.kept_count;
+    const uint32_t seg_k0 = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg]);
+    const uint32_t seg_cnt = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg + 1u]) - seg_k0;
+    const bool last_seg = seg + 1u == n_seg;
+    const uint32_t R = a.record_size;
+    const uint64_t row_step = (uint64_t)row_groups * kWaves;
+    const uint64_t j0 = (uint64_t)row_group * kWaves + wave;
+    const uint64_t rows = j0 < a.n_variants ? (a.n_variants - j0 + row_step - 1ull) / row_step : 0ull;
+
+    if (seg_cnt == 0u) {
+        // nothing of this segment is kept; the last segment still owes every row its '\n' (:190)
+        if (last_seg)
+            for (uint64_t n = lane; n < rows; n += 64ull) a.out[(j0 + n * row_step) * a.out_stride + 4ull * K] = (uint8_t)'\n';
+        return;
+    }
+    for (uint32_t r = tid; r < seg_cnt + 8u; r += (uint32_t)kThreads)
+        s_idx[r] = r < seg_cnt ? (uint16_t)(a.kept_idx[seg_k0 + r] - seg * kSegSamples) : (uint16_t)0;  // 8 entries of slack for the flush's fifth code
+    __syncthreads();
+    if (rows == 0ull) return;
+
+    uint8_t *const stage = s_stage[wave];
+    // loads as in gt_scan_gather3_kernel: tiles before the record's last tile at scalar base + lane offset + immediate,
+    // the last tile (and tiles behind it) as one window pulled back into the record
+    const uint32_t tile0 = seg * kTilesPerSeg;
+    const uint32_t tail_t = (R - 1u) >> 10;
+    const uint32_t tail_b = tail_t * 1024u + lane * 16u;
+    const uint32_t tail_off = min(tail_b, R - 16u);
+    const uint32_t tail_shift = tail_b + 16u <= R ? 0u : min(tail_b - (R - 16u), 16u);
+    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg]) {
+        const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
+        const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
+        const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
+        const uint8_t *__restrict__ sub = rec + (uint64_t)tile0 * 1024u;
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) {
+            const uint8_t *src16 = tile0 + t < tail_t ? sub + lane * 16u + t * 1024u : rec + tail_off;
+            __builtin_memcpy(&dst[t], src16, 16);
+        }
+    };
+    auto emit_row = [&](uint64_t n, const v4u(&w)[kTilesPerSeg]) {
+        // park the row's segment bytes (segment byte b at stage[b])
+#pragma unroll
+        for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
+            v4u x = w[tile];
+            if (tile0 + tile == tail_t) {
+                uint64_t lo, hi;
+                window_halves(x, tail_shift, lo, hi);
+                x = v4u{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+            }
+            if (tile0 + tile <= tail_t) *reinterpret_cast<v4u *>(stage + tile * 1024u + lane * 16u) = x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint8_t *const row_out = a.out + (j0 + n * row_step) * a.out_stride;
+        const uint64_t lo_emit = 4ull * seg_k0;
+        const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
+        const uint16_t *idx = s_idx;
+        flush_codes(
+            [stage, idx](uint32_t r) {
+                const uint32_t s16 = idx[r];  // r <= seg_cnt + 4: inside the slack
+                return ((uint32_t)stage[s16 >> 2] >> ((s16 & 3u) * 2u)) & 3u;  // src/pfile.rs:171-175
+            },
+            0u, row_out, lo_emit, hi_emit, seg_k0, K, lane);
+        // the stage is rewritten by the next row: this row's reads must have returned first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto landed = [&](const v4u(&w)[kTilesPerSeg]) {
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) asm volatile("" ::"v"(w[t].x), "v"(w[t].y), "v"(w[t].z), "v"(w[t].w));
+    };
+    // two register buffers, the loop unrolled by two: the next row's loads are in flight while this row's text goes out
+    v4u b0[kTilesPerSeg], b1[kTilesPerSeg];
+    load_row(0ull, b0);
+    for (uint64_t n = 0;;) {
+        landed(b0);
+        load_row(n + 1ull, b1);
+        emit_row(n, b0);
+        if (++n == rows) break;
+        landed(b1);
+        load_row(n + 1ull, b0);
+        emit_row(n, b1);
+        if (++n == rows) break;
+    }
+}
+
 }  // namespace
 
 // Every block walks the same number of rows, so the launch must be exactly ONE resident round: a grid
@@ -673,9 +790,13 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hi
         hipLaunchKernelGGL(k3, dim3((uint32_t)(groups * n_super)), dim3(kThreads), 0, stream, a, sc, n_seg_eff, n_super, (uint32_t)groups);
         return hipGetLastError();
     }
+    const char *ep = getenv("PGENHIP_SCAN_PICK");  // A/B: 0 = per-lane ctz compaction for medium densities as well
+    const bool pick_kernel = !batch_kernel && !dense && a.kept_idx != nullptr && sc.max_seg_count <= kPickMaxSegCodes && (ep ? atoi(ep) != 0 : true);
     void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t);
     if (batch_kernel)
         kern = a.variant_idx ? gt_scan_gather_kernel<true> : gt_scan_gather_kernel<false>;
+    else if (pick_kernel)
+        kern = a.variant_idx ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
     else if (a.variant_idx)
         kern = dense ? gt_scan_kernel<true, true> : gt_scan_kernel<true, false>;
     else
