@@ -23,6 +23,7 @@ struct pgenhip_ctx {
     uint32_t record_size = 0;
     uint32_t kept_count = 0;
     bool subset = false;
+    bool identity = false;             // a kept list that names every sample: AUTO takes the all-samples kernels
     uint32_t *d_kept = nullptr;
     uint64_t *d_keep_words = nullptr;  // scan kernel: keep bitmap, zero-padded to whole segments
     uint32_t *d_seg_rank = nullptr;    // scan kernel: kept samples before each segment
@@ -155,6 +156,7 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
     ctx->sample_count = sample_count;
     ctx->record_size = pgenhip_variant_record_size(sample_count);
     ctx->subset = kept_idx != nullptr;
+    ctx->identity = kept_idx != nullptr && kept_count == sample_count;  // strictly ascending and complete = 0..N-1
     ctx->kept_count = kept_idx ? kept_count : sample_count;
 
     int rc = PGENHIP_OK;
@@ -282,7 +284,8 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
     const uint32_t which = flags & PGENHIP_KERNEL_MASK;
     switch (which) {
         case PGENHIP_KERNEL_AUTO:
-            if (ctx->subset) {
+            if (ctx->identity) a.kept_idx = nullptr;  // `--include-sam` that keeps everybody: same bytes, the all-samples kernels
+            if (ctx->subset && !ctx->identity) {
                 // measured crossover (profiles/r01_kernel_sweeps.md, probe17: scan wins at 1 % kept, the gather at 0.1 %): with very sparse masks on long
                 // records the list gather touches only the kept samples' lines and wins; everywhere else the
                 // scan + LDS-compaction kernel does (it reads each record once with wide loads)
@@ -359,6 +362,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
     a.max_line_bytes = max_prefix_bytes + 4ull * ctx->kept_count + 1ull;
     switch (flags) {
         case PGENHIP_KERNEL_AUTO:
+            if (ctx->identity) a.kept_idx = nullptr;
             // all samples kept and rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place
             // behind their prefixes (+ a small prefix copy); otherwise the general kernel assembles whole lines
             if (gt_wide_lines_applicable(a)) HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
