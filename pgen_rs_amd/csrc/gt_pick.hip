@@ -53,11 +53,14 @@ __device__ __forceinline__ void split_offset(uint32_t o, const PickParams &p, ui
     pos = o - i * p.row_bytes;
 }
 
-// 2-bit code of kept sample `rank` of staged row `row` (ranks outside 0..K-1 are clamped: their bytes are never stored)
+// 2-bit code of kept sample `rank` of staged row `row`.  `idx` points at table entry 0; the table has kPadBefore
+// entries of slack in front and kPadAfter behind (ranks -4 .. K+4 occur next to a row's ends: their bytes are
+// never stored), so no clamp is needed.
+constexpr uint32_t kPadBefore = 4, kPadAfter = 12;
 __device__ __forceinline__ uint32_t pick_code(const uint8_t *row, const uint16_t *idx, int32_t rank, uint32_t K)
 {
-    const uint32_t r = (uint32_t)max(0, min(rank, (int32_t)K - 1));
-    const uint32_t s = idx[r];
+    (void)K;
+    const uint32_t s = idx[rank];
     return ((uint32_t)row[s >> 2] >> ((s & 3u) * 2u)) & 3u;
 }
 
@@ -82,15 +85,17 @@ __device__ __forceinline__ u32x4 pick_text16(const uint8_t *row, const uint16_t 
 template <bool HAS_VIDX>
 __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParams p)
 {
-    __shared__ uint16_t s_idx[kMaxSamples];
+    __shared__ uint16_t s_tab[kPadBefore + kMaxSamples + kPadAfter];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t K = a.kept_count;
-    for (uint32_t r = tid; r < K; r += (uint32_t)kThreads) s_idx[r] = (uint16_t)a.kept_idx[r];
+    for (uint32_t r = tid; r < kPadBefore + K + kPadAfter; r += (uint32_t)kThreads)
+        s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? (uint16_t)a.kept_idx[r - kPadBefore] : (uint16_t)0;
     __syncthreads();
+    const uint16_t *const s_idx = s_tab + kPadBefore;
 
     uint8_t *const stage = s_stage[wave];
     const uint32_t R = a.record_size;
