@@ -114,8 +114,9 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
  * max_prefix_bytes is a host-known upper bound of any prefix length (sizes the grid).
  * flags: PGENHIP_KERNEL_AUTO (all samples kept and sample_count >= 1024: the work-queue
  * stream kernel writes each GT segment in place behind its prefix and a small kernel copies
- * the prefixes; otherwise the general kernel), PGENHIP_KERNEL_ROWS or PGENHIP_KERNEL_WIDE to
- * force one of the two (tests, A/B). */
+ * the prefixes; a kept subset on records of >= 16 bytes: the scan-family kernels write the GT
+ * segments and the same small kernel the prefixes; otherwise the general kernel),
+ * PGENHIP_KERNEL_ROWS, PGENHIP_KERNEL_WIDE or PGENHIP_KERNEL_SCAN to force one (tests, A/B). */
 int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
                        const uint32_t *d_variant_idx, uint32_t n_variants,
                        const void *d_prefix_blob, const uint64_t *d_prefix_off,

@@ -365,8 +365,17 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             if (ctx->identity) a.kept_idx = nullptr;
             // all samples kept and rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place
             // behind their prefixes (+ a small prefix copy); otherwise the general kernel assembles whole lines
-            if (gt_wide_lines_applicable(a)) HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
-            else HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            if (gt_wide_lines_applicable(a)) {
+                HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+            } else if (a.kept_idx != nullptr && ctx->record_size >= 16u &&
+                       !(ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 128ull <= ctx->sample_count)) {
+                // kept subset: the scan-family kernels write each GT segment behind its prefix, the prefix kernel the rest
+                ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
+                HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
+                HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+            } else {
+                HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            }
             return PGENHIP_OK;
         case PGENHIP_KERNEL_ROWS:
             HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
@@ -375,8 +384,15 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             if (!gt_wide_lines_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_WIDE needs all samples kept and sample_count >= 1024");
             HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
+        case PGENHIP_KERNEL_SCAN: {
+            if (!ctx->subset || ctx->record_size < 16u) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_SCAN needs a kept-sample list and N >= 61");
+            ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
+            HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
+            HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        }
         default:
-            return fail(PGENHIP_ERR_BAD_ARG, "pgenhip_emit_lines supports kernel flags AUTO, ROWS and WIDE");
+            return fail(PGENHIP_ERR_BAD_ARG, "pgenhip_emit_lines supports kernel flags AUTO, ROWS, WIDE and SCAN");
     }
 }
 

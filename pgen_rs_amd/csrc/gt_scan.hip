@@ -38,6 +38,15 @@ constexpr uint32_t kFlushCodes = 2048;                  // pending codes that tr
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
+// Byte 0 of row j's GT segment: out + j * out_stride, or — full-line mode (src/pfile.rs:156-192), any kept
+// subset — behind the line's prefix at out + line_off[j] + prefix length (the prefixes are copied by
+// copy_prefixes_kernel, gt_wide.hip).  j is wave-uniform or per-lane.
+__device__ __forceinline__ uint8_t *row_text(const EmitArgs &a, uint64_t j)
+{
+    if (a.line_off != nullptr) return a.out + a.line_off[j] + (a.prefix_off[j + 1ull] - a.prefix_off[j]);
+    return a.out + j * a.out_stride;
+}
+
 template <uint32_t RING = kRing>
 __device__ __forceinline__ uint32_t ring_code(const uint8_t *ring, uint32_t rel)
 {
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
         for (uint32_t t = 0; t < kTilesPerSeg; t++) asm volatile("" ::"v"(cur[t].x), "v"(cur[t].y), "v"(cur[t].z), "v"(cur[t].w));
         if (more) load_row(j_next, nxt);
 
-        uint8_t *const row_out = a.out + j * a.out_stride;    // byte 0 of this row's GT segment
+        uint8_t *const row_out = row_text(a, j);               // byte 0 of this row's GT segment
         const uint64_t row_addr = (uint64_t)(uintptr_t)row_out;
         uint64_t emitted = 4ull * seg_k0;                      // next row byte this wave must write
         uint32_t produced = 0u;                                // codes in the ring (rank relative to seg_k0)
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather_kernel(EmitArgs a, Sc
     if (seg_cnt == 0u) {
         // nothing of this segment is kept; the last segment still owes every row its '\n' (:190)
         if (last_seg)
-            for (uint64_t n = lane; n < rows; n += 64ull) a.out[(j0 + n * row_step) * a.out_stride + 4ull * K] = (uint8_t)'\n';
+            for (uint64_t n = lane; n < rows; n += 64ull) row_text(a, j0 + n * row_step)[4ull * K] = (uint8_t)'\n';
         return;
     }
 
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather_kernel(EmitArgs a, Sc
         }
         // ---- flush the batch
         for (; flushed < n; flushed++) {
-            uint8_t *const row_out = a.out + (j0 + flushed * row_step) * a.out_stride;
+            uint8_t *const row_out = row_text(a, j0 + flushed * row_step);
             const uint64_t lo_emit = 4ull * seg_k0;
             const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
             flush_range<kGatherRing>(ring, (uint32_t)flushed * seg_cnt, row_out, lo_emit, hi_emit, seg_k0, K, lane);
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
     if (seg_cnt == 0u) {
         // nothing of these segments is kept; the last block of a row still owes the '\n' (:190)
         if (last_seg)
-            for (uint64_t n = lane; n < rows; n += 64ull) a.out[(j0 + n * row_step) * a.out_stride + 4ull * K] = (uint8_t)'\n';
+            for (uint64_t n = lane; n < rows; n += 64ull) row_text(a, j0 + n * row_step)[4ull * K] = (uint8_t)'\n';
         return;
     }
     if (tid == 0u) s_live = 0u;
@@ -632,7 +641,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
         // ---- flush the batch: one run of text per row
 #pragma nounroll
         for (; flushed < n; flushed++) {
-            uint8_t *const row_out = a.out + (j0 + flushed * row_step) * a.out_stride;
+            uint8_t *const row_out = row_text(a, j0 + flushed * row_step);
             const uint64_t lo_emit = 4ull * seg_k0;
             const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
             flush_range<kGatherRing>(ring, (uint32_t)flushed * seg_cnt, row_out, lo_emit, hi_emit, seg_k0, K, lane);
@@ -676,7 +685,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     if (seg_cnt == 0u) {
         // nothing of this segment is kept; the last segment still owes every row its '\n' (:190)
         if (last_seg)
-            for (uint64_t n = lane; n < rows; n += 64ull) a.out[(j0 + n * row_step) * a.out_stride + 4ull * K] = (uint8_t)'\n';
+            for (uint64_t n = lane; n < rows; n += 64ull) row_text(a, j0 + n * row_step)[4ull * K] = (uint8_t)'\n';
         return;
     }
     for (uint32_t r = tid; r < seg_cnt + 8u; r += (uint32_t)kThreads)
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint8_t *const row_out = a.out + (j0 + n * row_step) * a.out_stride;
+        uint8_t *const row_out = row_text(a, j0 + n * row_step);
         const uint64_t lo_emit = 4ull * seg_k0;
         const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
         const uint16_t *idx = s_idx;

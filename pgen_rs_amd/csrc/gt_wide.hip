@@ -672,6 +672,15 @@ bool gt_wide_applicable(const EmitArgs &a)
            (a.n_variants <= 1 || a.out_stride == 4ull * a.kept_count + 1ull);
 }
 
+hipError_t launch_copy_prefixes(const EmitArgs &a, int num_cus, hipStream_t stream)
+{
+    if (a.n_variants == 0 || a.line_off == nullptr || a.prefix_blob == nullptr) return hipGetLastError();
+    const uint64_t blocks_needed = ((uint64_t)a.n_variants * 16ull + 255ull) / 256ull;
+    const uint64_t pcap = (uint64_t)num_cus * 8ull;
+    hipLaunchKernelGGL(copy_prefixes_kernel, dim3((uint32_t)(blocks_needed < pcap ? blocks_needed : pcap)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 bool gt_wide_lines_applicable(const EmitArgs &a)
 {
     // full lines through the work-queue stream kernel: all samples kept, rows of >= 4 KiB, queue heads present
@@ -727,12 +736,7 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
         const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
         const uint32_t g = (uint32_t)(need < cap ? need : cap);
         hipLaunchKernelGGL(dk, dim3(g), dim3(512), 0, stream, a, p);
-        if (a.line_off && a.prefix_blob) {
-            // the prefixes: disjoint bytes, same stream, any order
-            const uint64_t blocks_needed = ((uint64_t)a.n_variants * 16ull + 255ull) / 256ull;
-            const uint64_t pcap = (uint64_t)num_cus * 8ull;
-            hipLaunchKernelGGL(copy_prefixes_kernel, dim3((uint32_t)(blocks_needed < pcap ? blocks_needed : pcap)), dim3(256), 0, stream, a);
-        }
+        if (a.line_off) return launch_copy_prefixes(a, num_cus, stream);  // the prefixes: disjoint bytes, same stream, any order
         return hipGetLastError();
     }
     if (stream_ns == 3 || stream_ns == 7) {

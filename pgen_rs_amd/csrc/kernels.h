@@ -36,6 +36,7 @@ hipError_t launch_gt_flat(const EmitArgs &a, int num_cus, hipStream_t stream);
 // Same contract as the flat kernel, but a wave stages its span's record bytes with one wide
 // (16 B/lane) load into LDS and then issues 16 coalesced 1-KiB stores (rows >= 4 KiB of text).
 bool gt_wide_applicable(const EmitArgs &a);
+hipError_t launch_copy_prefixes(const EmitArgs &a, int num_cus, hipStream_t stream);  // full-line mode: prefix bytes of every line
 bool gt_wide_lines_applicable(const EmitArgs &a);  // full-line mode (line_off/prefix_off set) through the stream kernel
 hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream);
 

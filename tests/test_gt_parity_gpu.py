@@ -341,6 +341,42 @@ def test_emit_lines_stream_kernel(n, v, kernel):
         assert (got[out_offset + want.size :] == SENTINEL).all()
 
 
+@pytest.mark.parametrize("n,frac", [(2504, 0.01), (2504, 0.5), (40000, 0.01), (40000, 0.3), (40000, 0.9), (120000, 0.004), (120000, 0.02)])
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_AUTO, _capi.KERNEL_SCAN, _capi.KERNEL_ROWS])
+def test_emit_lines_kept_subsets(n, frac, kernel):
+    """Full lines with a sample filter: every scan-family kernel (per-row, dense, segment pick, one- and
+    three-segment gather, chosen by density and N) writes its GT segments behind the prefixes and
+    the prefix kernel fills those in; same bytes as the general kernel and the oracle, with a
+    gapped variant list and sentinel bytes around the output."""
+    rng = np.random.default_rng(int(700 + n + 1000 * frac))
+    v = 150
+    v_file = v + 9
+    r = oracle.variant_record_size(n)
+    recs = rng.integers(0, 256, size=v_file * r, dtype=np.uint8)
+    vidx = np.sort(rng.choice(v_file, size=v, replace=False))
+    kept = np.sort(rng.choice(n, size=max(4, int(n * frac)), replace=False)).astype(np.uint32)
+    k = int(kept.size)
+    prefixes = [bytes(rng.integers(33, 127, size=int(rng.integers(0, 60)) if i % 5 else 0, dtype=np.uint8)) for i in range(v)]
+    blob = np.frombuffer(b"".join(prefixes) + b"!", dtype=np.uint8)
+    poff = np.cumsum([0] + [len(q) for q in prefixes]).astype(np.int64)
+    loff = np.cumsum([0] + [len(q) + 4 * k + 1 for q in prefixes]).astype(np.int64)
+    want = oracle.emit_lines(recs, v, n, blob, poff.astype(np.uint64), loff.astype(np.uint64), kept_idx=kept, variant_idx=vidx)
+    out_offset = 7
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        out = torch.full((out_offset + int(loff[-1]) + 48,), SENTINEL, dtype=torch.uint8, device=DEV)
+        eng.emit_lines(torch.from_numpy(recs).to(DEV), v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV),
+                       torch.from_numpy(loff).to(DEV), 60, out[out_offset:],
+                       variant_idx=torch.tensor(vidx, dtype=torch.int32, device=DEV), kernel=kernel)
+        eng.wait()
+        got = out.cpu().numpy()
+    assert (got[:out_offset] == SENTINEL).all()
+    body = got[out_offset : out_offset + want.size]
+    if bytes(body) != want.tobytes():
+        bad = np.flatnonzero(body != want)
+        raise AssertionError(f"n={n} frac={frac} kernel={kernel}: {bad.size} bytes differ, first at {bad[:6]}")
+    assert (got[out_offset + want.size :] == SENTINEL).all()
+
+
 def test_device_synth_matches_oracle_twin():
     for n, v, first, stride_pad, dirty in [(2504, 33, 0, 0, False), (10007, 9, 123, 3, True), (5, 4, 2**31, 0, False), (500000, 2, 999_999, 0, False)]:
         r = oracle.variant_record_size(n)
