@@ -116,7 +116,7 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
  * stream kernel writes each GT segment in place behind its prefix and a small kernel copies
  * the prefixes; a kept subset on records of >= 16 bytes: the scan-family kernels write the GT
  * segments and the same small kernel the prefixes; otherwise the general kernel),
- * PGENHIP_KERNEL_ROWS, PGENHIP_KERNEL_WIDE or PGENHIP_KERNEL_SCAN to force one (tests, A/B). */
+ * PGENHIP_KERNEL_ROWS, PGENHIP_KERNEL_WIDE, PGENHIP_KERNEL_SCAN or PGENHIP_KERNEL_PICK to force one (tests, A/B). */
 int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
                        const uint32_t *d_variant_idx, uint32_t n_variants,
                        const void *d_prefix_blob, const uint64_t *d_prefix_off,

@@ -367,6 +367,10 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             // behind their prefixes (+ a small prefix copy); otherwise the general kernel assembles whole lines
             if (gt_wide_lines_applicable(a)) {
                 HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+            } else if (gt_pick_applicable(a)) {
+                // kept subset on short records: the pick kernel flushes each parked row behind its prefix
+                HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
+                HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             } else if (a.kept_idx != nullptr && ctx->record_size >= 16u &&
                        !(ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 128ull <= ctx->sample_count)) {
                 // kept subset: the scan-family kernels write each GT segment behind its prefix, the prefix kernel the rest
@@ -391,8 +395,13 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         }
+        case PGENHIP_KERNEL_PICK:
+            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_PICK needs a kept-sample list with K >= 4 and 61 <= N <= 4096");
+            HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
+            HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
         default:
-            return fail(PGENHIP_ERR_BAD_ARG, "pgenhip_emit_lines supports kernel flags AUTO, ROWS, WIDE and SCAN");
+            return fail(PGENHIP_ERR_BAD_ARG, "pgenhip_emit_lines supports kernel flags AUTO, ROWS, WIDE, SCAN and PICK");
     }
 }
 

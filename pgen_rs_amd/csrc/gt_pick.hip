@@ -19,7 +19,9 @@
 //     usual text dwords and funnel shift (:177-190).  A chunk that holds a row's '\n' merges the
 //     tail of row i with the head of row i+1 in registers, so it is still one 16-B store;
 //   * the run's first and last partial chunk (shared with the neighbouring waves' runs) go out as
-//     ONE byte-store instruction (lanes 0-15 head bytes, 16-31 tail bytes).
+//     ONE byte-store instruction (lanes 0-15 head bytes, 16-31 tail bytes);
+//   * full-line mode (pgenhip_emit_lines): the rows sit behind their prefixes, so each parked row
+//     is flushed on its own through flush_codes with the same table + staged-byte pick.
 // HBM traffic per row: the record once + 4K+1 bytes of text; the kept list once per block.
 #include "gt_common.hip.h"
 #include "kernels.h"
@@ -82,7 +84,7 @@ __device__ __forceinline__ u32x4 pick_text16(const uint8_t *row, const uint16_t 
     return v;
 }
 
-template <bool HAS_VIDX>
+template <bool HAS_VIDX, bool LINES>
 __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParams p)
 {
     __shared__ uint16_t s_tab[kPadBefore + kMaxSamples + kPadAfter];
@@ -149,9 +151,24 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- emit: one contiguous run of rows_here x S bytes
         const uint64_t row0 = (uint64_t)bi * B;
         const uint32_t rows_here = (uint32_t)min((uint64_t)B, (uint64_t)a.n_variants - row0);
+        if (LINES) {
+            // ---- full-line mode: the rows' GT segments sit behind their prefixes, so every row is flushed on its own
+            // (whole aligned chunks + one byte-store instruction for its two edges; flush_codes, gt_common.hip.h)
+            for (uint32_t i = 0; i < rows_here; i++) {
+                const uint8_t *row = stage + i * p.pitch;
+                const uint16_t *idx = s_idx;
+                flush_codes([row, idx, K](uint32_t r) { return pick_code(row, idx, (int32_t)r, K); }, 0u, row_text(a, row0 + i), 0ull,
+                            (uint64_t)S, 0u, K, lane);
+            }
+            if (!more) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            bi = bi_next;
+            continue;
+        }
+        // ---- emit: one contiguous run of rows_here x S bytes
         const uint32_t len = rows_here * S;
         uint8_t *const run = a.out + row0 * (uint64_t)S;
         const uint32_t mis = (uint32_t)(uintptr_t)run & 15u;
@@ -210,9 +227,9 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
 bool gt_pick_applicable(const EmitArgs &a)
 {
     // kept subset, record of one tile (16 <= R <= 1024), rows of >= 17 bytes (a 16-B chunk then touches at most two
-    // rows), dense output pitch, no full-line mode
-    return a.kept_idx != nullptr && a.line_off == nullptr && a.sample_count <= kMaxSamples && a.record_size >= 16u &&
-           a.kept_count >= 4u && (a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull);
+    // rows), dense output pitch or full-line mode (rows then go out one by one behind their prefixes)
+    return a.kept_idx != nullptr && a.sample_count <= kMaxSamples && a.record_size >= 16u && a.kept_count >= 4u &&
+           (a.line_off != nullptr || a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull);
 }
 
 hipError_t launch_gt_pick(const EmitArgs &a, int num_cus, hipStream_t stream)
@@ -233,7 +250,11 @@ hipError_t launch_gt_pick(const EmitArgs &a, int num_cus, hipStream_t stream)
     p.batch_rows = b;
     p.magic = (uint32_t)(0x100000000ull / p.row_bytes) + 1u;    // exact up to one compare for run offsets < 12 * 16 385 < 2^20
     p.n_batches = (uint32_t)(((uint64_t)a.n_variants + b - 1u) / b);
-    void (*kern)(EmitArgs, PickParams) = a.variant_idx ? gt_pick_kernel<true> : gt_pick_kernel<false>;
+    void (*kern)(EmitArgs, PickParams);
+    if (a.line_off)
+        kern = a.variant_idx ? gt_pick_kernel<true, true> : gt_pick_kernel<false, true>;
+    else
+        kern = a.variant_idx ? gt_pick_kernel<true, false> : gt_pick_kernel<false, false>;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     const uint64_t need = ((uint64_t)p.n_batches + kWaves - 1ull) / kWaves;

@@ -38,15 +38,6 @@ constexpr uint32_t kFlushCodes = 2048;                  // pending codes that tr
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-// Byte 0 of row j's GT segment: out + j * out_stride, or — full-line mode (src/pfile.rs:156-192), any kept
-// subset — behind the line's prefix at out + line_off[j] + prefix length (the prefixes are copied by
-// copy_prefixes_kernel, gt_wide.hip).  j is wave-uniform or per-lane.
-__device__ __forceinline__ uint8_t *row_text(const EmitArgs &a, uint64_t j)
-{
-    if (a.line_off != nullptr) return a.out + a.line_off[j] + (a.prefix_off[j + 1ull] - a.prefix_off[j]);
-    return a.out + j * a.out_stride;
-}
-
 template <uint32_t RING = kRing>
 __device__ __forceinline__ uint32_t ring_code(const uint8_t *ring, uint32_t rel)
 {
@@ -122,46 +113,6 @@ __device__ __forceinline__ void window_halves(const v4u &w, uint32_t tail_shift,
 // chunk (segment / row edges, shared with the neighbouring segment's block) go out as ONE
 // byte-store instruction: lanes 0-15 take the head bytes, lanes 16-31 the tail bytes.
 // All 64-bit arithmetic is wave-uniform (scalar unit); a lane only adds a 32-bit offset.
-// `code_of(x)` yields the 2-bit code at position x = base + segment rank (ring position, or rank for the pick kernel).
-template <typename CodeFn>
-__device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
-                                            uint32_t seg_k0, uint32_t K, uint32_t lane)
-{
-    uint8_t *const out0 = row_out + emitted;                           // first byte of the flush
-    const uint32_t len = (uint32_t)(hi_emit - emitted);                // <= 4 * 16 384 + 1
-    const uint32_t mis = (uint32_t)(uintptr_t)out0 & 15u;
-    const uint32_t head = min((16u - mis) & 15u, len);                 // bytes before the first whole chunk
-    const uint32_t n_chunks = (len - head) >> 4;
-    const uint32_t tail_off = head + (n_chunks << 4);
-    const uint32_t tail = len - tail_off;                              // bytes after the last whole chunk (< 16)
-    const uint32_t e4 = base + (uint32_t)(emitted >> 2) - seg_k0;      // position of the code under byte `emitted`
-    const uint32_t em = (uint32_t)emitted & 3u;
-    const uint64_t nl64 = 4ull * K - emitted;                          // flush offset of the row's '\n' (row byte 4K)
-    const uint32_t nl = nl64 < (uint64_t)len ? (uint32_t)nl64 : 0xFFFFFFFFu;
-    for (uint32_t i = lane; i < n_chunks; i += 64u) {
-        const uint32_t off = head + (i << 4);
-        const uint32_t x = em + off;                                   // byte offset from the dword boundary under `emitted`
-        const uint32_t rel = e4 + (x >> 2);
-        const uint32_t sh = x & 3u;
-        const uint32_t t0 = gt_text(code_of(rel));
-        const uint32_t t1 = gt_text(code_of(rel + 1u));
-        const uint32_t t2 = gt_text(code_of(rel + 2u));
-        const uint32_t t3 = gt_text(code_of(rel + 3u));
-        const uint32_t t4 = gt_text(code_of(rel + 4u));  // may be past the flush: then it feeds no byte (sh = 0) or only '\n''s place
-        v4u v = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
-        // the row's '\n' can only be a whole chunk's last byte (hi_emit <= 4K + 1)
-        if (off + 15u == nl) v.w = (v.w & 0x00FFFFFFu) | 0x0A000000u;
-        *reinterpret_cast<v4u *>(out0 + off) = v;
-    }
-    const uint32_t off = lane < 16u ? lane : tail_off + (lane - 16u);
-    const bool on = lane < 16u ? lane < head : (lane < 32u && lane - 16u < tail);
-    if (on) {
-        const uint32_t x = em + off;
-        const uint32_t code = code_of(e4 + (x >> 2));
-        out0[off] = (uint8_t)(off == nl ? 0x0Au : gt_text_byte(code, x & 3u));
-    }
-}
-
 template <uint32_t RING = kRing>
 __device__ __forceinline__ void flush_range(const uint8_t *ring, uint32_t ring_base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
                                             uint32_t seg_k0, uint32_t K, uint32_t lane)

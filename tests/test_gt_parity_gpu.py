@@ -342,12 +342,14 @@ def test_emit_lines_stream_kernel(n, v, kernel):
 
 
 @pytest.mark.parametrize("n,frac", [(2504, 0.01), (2504, 0.5), (40000, 0.01), (40000, 0.3), (40000, 0.9), (120000, 0.004), (120000, 0.02)])
-@pytest.mark.parametrize("kernel", [_capi.KERNEL_AUTO, _capi.KERNEL_SCAN, _capi.KERNEL_ROWS])
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_AUTO, _capi.KERNEL_SCAN, _capi.KERNEL_ROWS, _capi.KERNEL_PICK])
 def test_emit_lines_kept_subsets(n, frac, kernel):
     """Full lines with a sample filter: every scan-family kernel (per-row, dense, segment pick, one- and
     three-segment gather, chosen by density and N) writes its GT segments behind the prefixes and
     the prefix kernel fills those in; same bytes as the general kernel and the oracle, with a
     gapped variant list and sentinel bytes around the output."""
+    if kernel == _capi.KERNEL_PICK and n > 4096:
+        pytest.skip("pick kernel: short records only")
     rng = np.random.default_rng(int(700 + n + 1000 * frac))
     v = 150
     v_file = v + 9
