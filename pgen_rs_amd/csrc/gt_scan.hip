@@ -603,15 +603,17 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
 }
 
 // ---------------------------------------------------------------------------------------------
-// gt_scan_pick_kernel — kept subsets of MEDIUM density on long records (more kept samples per
-// segment than the gather kernels' rings take, at most 75 % kept).  The per-lane ctz compaction of
+// gt_scan_pick_kernel — kept subsets of MEDIUM and HIGH density on long records (more kept samples
+// per segment than the gather kernels' rings take).  The per-lane ctz compaction of
 // gt_scan_kernel costs 150-300 VALU instructions per store step there; this kernel has no
 // compaction at all (the idea of gt_pick.hip, per segment): the block's slice of the context's
 // kept list, as u16 offsets into the segment, IS the rank -> sample table in LDS; a wave parks a
 // row's 4 KiB of record bytes in its LDS stage and the output-driven flush (flush_codes) picks
 // every genotype straight from there: one table read + one staged-byte read per genotype.
-// A row piece is >= 4 KiB of text here, so the one store drain per row piece is amortised.
-constexpr uint32_t kPickMaxSegCodes = kSegSamples * 3u / 4u;   // 12 288 table entries = 24 KiB of LDS
+// A row piece is >= 4 KiB of text here, so the one store drain per row piece is amortised.  Against the DENSE
+// instantiation of gt_scan_kernel (> 75 % kept: whole record bytes per step) it is 4-6 % faster as well
+// (0.545 -> 0.566 of roofline at all-but-7 kept), so gt_scan_kernel is only the A/B partner now.
+constexpr uint32_t kPickMaxSegCodes = kSegSamples;             // up to a fully kept segment: 32 KiB of LDS for the table
 
 template <bool HAS_VIDX>
 __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups)
@@ -751,7 +753,7 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hi
         return hipGetLastError();
     }
     const char *ep = getenv("PGENHIP_SCAN_PICK");  // A/B: 0 = per-lane ctz compaction for medium densities as well
-    const bool pick_kernel = !batch_kernel && !dense && a.kept_idx != nullptr && sc.max_seg_count <= kPickMaxSegCodes && (ep ? atoi(ep) != 0 : true);
+    const bool pick_kernel = !batch_kernel && a.kept_idx != nullptr && sc.max_seg_count <= kPickMaxSegCodes && (ep ? atoi(ep) != 0 : true);
     void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t);
     if (batch_kernel)
         kern = a.variant_idx ? gt_scan_gather_kernel<true> : gt_scan_gather_kernel<false>;
