@@ -269,196 +269,32 @@ __global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs 
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// gt_scan_gather_kernel — the scan kernel for SPARSE keeps (read-dominated runs such as BASELINE
-// config 5: 1 % of 500 000 samples kept, 125 KB read and 20 KB written per variant).
-//
-// Two measured limits of gt_scan_kernel shaped it (config-5 geometry, profiles/r01_kernel_sweeps.md):
-//  (1) gfx9 counts loads and stores in ONE in-order vmcnt, and a wave's flush stores are its
-//      youngest memory operations when it comes back for the next row's record words: every row
-//      pays a store round trip.
-//  (2) the per-lane ctz loop over the lane's own keep bits runs as long as the fullest lane of the
-//      wave (3-4 rounds at 1 % kept for 0.64 kept samples per lane on average): 330 VALU
-//      instructions per 4-KiB row segment, and a CDNA SIMD retires one wave64 VALU instruction
-//      per four cycles — the kernel was VALU-bound at 46 % of the read roofline.
-// Here
-//   * the block turns its segment's keep words ONCE into a rank -> sample-index table in LDS
-//     (ballot/popcount prefix as before, then one ctz loop per block instead of one per row);
-//   * a wave keeps record words for THREE rows in registers (re-loaded three rows ahead as soon
-//     as a buffer has been parked; the loop is unrolled by three so no register copies sit
-//     between a load and its use) and, inside a batch, issues
-//     nothing but loads, so the compiler's vmcnt waits are exact there;
-//   * per row it parks the segment's record bytes in its LDS stage (one ds_write_b128 per tile)
-//     and lane r fetches kept sample r's code straight from the stage: work proportional to the
-//     number of KEPT samples, all lanes busy;
-//   * codes go to the wave's LDS ring at a RUNNING position (row n's rank r sits at
-//     n * seg_cnt + r); the whole batch (up to 48 rows) is flushed at once, two store
-//     instructions per row (flush_range), so the one store drain per batch overlaps the two rows
-//     of loads already in flight.
-// (A role split like gt_wide's — scan waves that only load, one storer wave per block — was
-// measured too: the storer's serial flush chain could not keep up with more than three scan waves.)
-// Launch precondition: every segment holds at most kGatherMaxSegCodes kept samples (host checks).
+// ---- constants of the sparse-keep gather kernel below -------------------------------------------
 constexpr uint32_t kGatherRing = 4096;                               // codes per wave
 constexpr uint32_t kGatherMaxRows = 48;                               // rows per batch (a store drain per batch)
 constexpr uint32_t kGatherMaxSegCodes = (kGatherRing - 8u) / 4u;     // >= 3 whole rows + the row being scanned fit the ring
 constexpr uint32_t kStageBytes = kSegSamples / 4u;                   // one row's segment of record bytes
 
-template <bool HAS_VIDX>
-__global__ __launch_bounds__(kThreads) void gt_scan_gather_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups)
-{
-    __shared__ uint64_t s_mask[kSegWords];
-    __shared__ uint32_t s_pre[kSegWords + 1];
-    __shared__ uint16_t s_idx[kGatherMaxSegCodes + 2];                // rank -> sample index inside the segment
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kWaves][kGatherRing];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t seg = blockIdx.x % n_seg;
-    const uint32_t row_group = blockIdx.x / n_seg;
-
-    stage_segment(sc, seg, s_mask, s_pre, tid);
-
-    const uint32_t K = a.kept_count;
-    const uint32_t seg_k0 = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg]);  // kept samples before this segment
-    const uint32_t seg_cnt = __builtin_amdgcn_readfirstlane(s_pre[kSegWords]);   // kept samples inside it
-    const bool last_seg = seg + 1u == n_seg;
-    const uint32_t seg_byte0 = seg * (kSegSamples / 4u);      // first record byte of the segment
-    const uint32_t R = a.record_size;
-    const uint64_t row_step = (uint64_t)row_groups * kWaves;
-    const uint64_t j0 = (uint64_t)row_group * kWaves + wave;
-    const uint64_t rows = j0 < a.n_variants ? (a.n_variants - j0 + row_step - 1ull) / row_step : 0ull;
-
-    if (seg_cnt == 0u) {
-        // nothing of this segment is kept; the last segment still owes every row its '\n' (:190)
-        if (last_seg)
-            for (uint64_t n = lane; n < rows; n += 64ull) row_text(a, j0 + n * row_step)[4ull * K] = (uint8_t)'\n';
-        return;
-    }
-
-    // ---- rank -> sample index, once per block: wave w lists tile w (kTilesPerSeg == kWaves)
-    static_assert(kTilesPerSeg == (uint32_t)kWaves, "one tile per wave in the index build");
-    uint32_t live_tiles = 0u;  // tiles with at least one kept sample (wave-uniform bit set)
-    {
-        uint64_t mm = s_mask[wave * 64u + lane];
-        uint32_t pos = s_pre[wave * 64u + lane];
-        while (mm != 0ull) {
-            const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
-            mm &= mm - 1ull;
-            s_idx[pos++] = (uint16_t)(wave * kTileSamples + lane * 64u + bit);
-        }
-#pragma unroll
-        for (uint32_t t = 0; t < kTilesPerSeg; t++)
-            if (__ballot(s_mask[t * 64u + lane] != 0ull) != 0ull) live_tiles |= 1u << t;
-    }
-    __syncthreads();
-    if (rows == 0ull) return;
-
-    uint8_t *const ring = s_ring[wave];
-    uint8_t *const stage = s_stage[wave];
-    uint32_t tail_shift[kTilesPerSeg];
-#pragma unroll
-    for (uint32_t t = 0; t < kTilesPerSeg; t++) {
-        const uint32_t b = seg_byte0 + t * 1024u + lane * 16u;
-        tail_shift[t] = b + 16u <= R ? 0u : min(b - (R - 16u), 16u);
-    }
-    // branch-free loads (see gt_scan_kernel); rows past the end re-load the last row, so every stage
-    // issues the same number of loads and the compiler's vmcnt bookkeeping stays exact
-    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg]) {
-        const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
-        const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
-        const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
-#pragma unroll
-        for (uint32_t t = 0; t < kTilesPerSeg; t++) {
-            const uint32_t b = min(seg_byte0 + t * 1024u + lane * 16u, R - 16u);
-            __builtin_memcpy(&dst[t], rec + b, 16);
-        }
-    };
-    uint32_t base = 0u;  // ring position of rank 0 of the row being scanned (mod 2^32; the ring size divides 2^32)
-    auto scan_row = [&](const v4u(&w)[kTilesPerSeg]) {
-        // park the record bytes of the live tiles (segment byte b at stage[b])
-#pragma unroll
-        for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
-            if (!(live_tiles & (1u << tile))) continue;
-            v4u x = w[tile];
-            if (tail_shift[tile] != 0u) {  // record tail: the window was pulled back; shift it into place
-                uint64_t lo, hi;
-                window_halves(x, tail_shift[tile], lo, hi);
-                x = v4u{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-            }
-            *reinterpret_cast<v4u *>(stage + tile * 1024u + lane * 16u) = x;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // lane r takes kept sample r (src/pfile.rs:171-175): byte idx / 4, bits 2 * (idx % 4)
-#pragma unroll 2
-        for (uint32_t r = lane; r < seg_cnt; r += 64u) {
-            const uint32_t idx = s_idx[r];
-            const uint32_t byte = stage[idx >> 2];
-            ring[(base + r) & (kGatherRing - 1u)] = (uint8_t)((byte >> ((idx & 3u) * 2u)) & 3u);
-        }
-        // the stage is rewritten by the next row: its reads above must have returned first
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        base += seg_cnt;
-    };
-    auto landed = [&](const v4u(&w)[kTilesPerSeg]) {
-#pragma unroll
-        for (uint32_t t = 0; t < kTilesPerSeg; t++) asm volatile("" ::"v"(w[t].x), "v"(w[t].y), "v"(w[t].z), "v"(w[t].w));
-    };
-
-    // rows per batch: a multiple of three (the register rotation), all of them plus the row being scanned in the ring
-    const uint32_t fit = (kGatherRing - 8u) / seg_cnt - 1u;              // >= 3 by the launch precondition
-    const uint64_t batch = (uint64_t)(min(fit, kGatherMaxRows) / 3u * 3u);
-    v4u b0[kTilesPerSeg], b1[kTilesPerSeg], b2[kTilesPerSeg];
-    load_row(0ull, b0);
-    load_row(1ull, b1);
-    load_row(2ull, b2);
-    uint64_t n = 0ull;       // rows scanned
-    uint64_t flushed = 0ull; // rows written
-    while (n < rows) {
-        const uint64_t batch_end = min(rows, n + batch);
-        // ---- scan: loads and LDS only; a buffer is re-loaded (three rows ahead) as soon as it has been
-        // parked, so all three are in flight while the batch's stores drain.  Leaving the triple early
-        // only happens at the very last row.
-        for (;;) {
-            landed(b0);
-            scan_row(b0);
-            load_row(n + 3ull, b0);
-            if (++n == batch_end) break;
-            landed(b1);
-            scan_row(b1);
-            load_row(n + 3ull, b1);
-            if (++n == batch_end) break;
-            landed(b2);
-            scan_row(b2);
-            load_row(n + 3ull, b2);
-            if (++n == batch_end) break;
-        }
-        // ---- flush the batch
-        for (; flushed < n; flushed++) {
-            uint8_t *const row_out = row_text(a, j0 + flushed * row_step);
-            const uint64_t lo_emit = 4ull * seg_k0;
-            const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
-            flush_range<kGatherRing>(ring, (uint32_t)flushed * seg_cnt, row_out, lo_emit, hi_emit, seg_k0, K, lane);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// gt_scan_gather3_kernel — gt_scan_gather_kernel with a block owning THREE consecutive segments
-// (49 152 samples, 12 KiB of every record).  Measured on the config-5 geometry, the 2 GB of text
-// cost as much as 6 GB would in a stream: a row's output arrives as 31 pieces of ~656 bytes from 31
-// different blocks at different times, every piece with two partly written 128-B lines.  Here a
-// wave writes a row's three pieces as ONE run (three times fewer, three times longer pieces), and
-// the register rotation needs no unrolled row loop: buffer q always holds sub-segment q and is
-// re-loaded with the NEXT row's sub-segment q as soon as it has been parked (prefetch distance =
-// one row piece).  The rank -> sample table comes straight from the kept list the context already
-// holds (ascending u32 indices, src/pfile.rs:319-333), so no bitmap is staged at all.
+// gt_scan_gather3_kernel — sparse keeps around 1 % on long records (BASELINE config 5: 1 % of
+// 500 000 samples kept, 125 KB read and 20 KB written per variant), where it is ~4 % ahead of the
+// segment pick kernel below; everywhere else that kernel is as fast or faster and is the default.
+//   * a block owns THREE consecutive segments (49 152 samples, 12 KiB of every record); its slice of
+//     the context's kept list (ascending u32 indices, src/pfile.rs:319-333) is the rank -> sample
+//     table in LDS (u16 offsets);
+//   * a wave keeps the three sub-segments of a row in three register buffers — buffer q always
+//     holds sub-segment q and is re-loaded with the NEXT row's sub-segment q as soon as it has been
+//     parked in the wave's LDS stage — and, inside a batch, issues nothing but loads, so the
+//     compiler's vmcnt waits are exact there (gfx9 counts loads and stores in ONE in-order vmcnt);
+//   * lane r fetches kept sample r's code straight from the stage (work proportional to the KEPT
+//     samples) into the wave's LDS code ring at a RUNNING position (row n's rank r at
+//     n * seg_cnt + r);
+//   * a whole batch of rows (up to 48) is flushed at once: per row one run of text (three segments'
+//     worth: a row's output arrives as 11 pieces instead of 31, with a third of the partly written
+//     128-B lines) = whole aligned 16-B stores + ONE byte-store instruction for its two edges, so
+//     the one store drain per batch overlaps the row of loads already in flight.
+// History (profiles/r01_kernel_sweeps.md): per-row ctz kernel 4.4 ms (two-round grid) -> 3.4 (one
+// round) -> one-segment gather + batched flush 3.05 -> this 2.9 ms on the config-5 geometry.
 // Launch precondition: at most kGatherMaxSegCodes kept samples in any aligned triple of segments.
 constexpr uint32_t kSubSegs = 3;
 constexpr uint32_t kSuperSamples = kSubSegs * kSegSamples;
@@ -603,8 +439,8 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
 }
 
 // ---------------------------------------------------------------------------------------------
-// gt_scan_pick_kernel — kept subsets of MEDIUM and HIGH density on long records (more kept samples
-// per segment than the gather kernels' rings take).  The per-lane ctz compaction of
+// gt_scan_pick_kernel — the default kernel for kept subsets on records longer than one tile, any
+// density.  The per-lane ctz compaction of
 // gt_scan_kernel costs 150-300 VALU instructions per store step there; this kernel has no
 // compaction at all (the idea of gt_pick.hip, per segment): the block's slice of the context's
 // kept list, as u16 offsets into the segment, IS the rank -> sample table in LDS; a wave parks a
@@ -699,6 +535,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
         for (uint32_t t = 0; t < kTilesPerSeg; t++) asm volatile("" ::"v"(w[t].x), "v"(w[t].y), "v"(w[t].z), "v"(w[t].w));
     };
     // two register buffers, the loop unrolled by two: the next row's loads are in flight while this row's text goes out
+    // (three buffers, re-loaded three rows ahead, measured no better: 3.20-3.35 vs 3.03-3.20 ms on the config-5 geometry)
     v4u b0[kTilesPerSeg], b1[kTilesPerSeg];
     load_row(0ull, b0);
     for (uint64_t n = 0;;) {
@@ -732,17 +569,16 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hi
     if (a.n_variants == 0) return hipSuccess;
     const uint32_t n_seg = (a.sample_count + kSegSamples - 1u) / kSegSamples;
     const uint32_t n_seg_eff = n_seg ? n_seg : 1u;
-    // gather kernels whenever the kept codes of a block's samples fit its ring four times over (sparse keeps:
-    // <= 6 % of a segment, <= 2 % of a segment triple); PGENHIP_SCAN_BATCH=0 forces the per-row kernel and
-    // PGENHIP_SCAN_SUPER=0 the one-segment gather kernel (A/B)
-    const char *es = getenv("PGENHIP_SCAN_BATCH");
-    const char *eu = getenv("PGENHIP_SCAN_SUPER");
-    const bool batch_on = es ? atoi(es) != 0 : true;
-    // (records shorter than three segments: the one-segment kernel — a triple block would issue 12 loads per row for 4 KiB or less)
-    const bool super_kernel = batch_on && a.kept_idx != nullptr && sc.max_super_count <= kGatherMaxSegCodes && (eu ? atoi(eu) != 0 : n_seg_eff >= kSubSegs);
-    const bool batch_kernel = batch_on && !super_kernel && sc.max_seg_count <= kGatherMaxSegCodes;
-    const bool dense = (uint64_t)a.kept_count * 4ull > (uint64_t)a.sample_count * 3ull;  // > 75 % kept
     const uint64_t groups_needed = ((uint64_t)a.n_variants + kWaves - 1ull) / kWaves;
+    // Three kernels (interleaved A/B in profiles/r01_kernel_sweeps.md):
+    //  * the segment pick kernel — default for every density;
+    //  * the three-segment gather kernel in the one band where it measured ahead (0.8-2 % kept on records of three
+    //    segments or more: config 5; 0.3 % / 0.6 % / 1 % / 2 % kept: pick 1.53 / 1.68 / 1.76 / 2.23 ms, gather 1.62 / 1.75 / 1.72 / 2.14); PGENHIP_SCAN_SUPER=0/1 overrides the band (1 still needs the ring precondition);
+    //  * the per-lane ctz kernel (DENSE instantiation above 75 % kept) as A/B partner: PGENHIP_SCAN_PICK=0.
+    const char *eu = getenv("PGENHIP_SCAN_SUPER");
+    const char *ep = getenv("PGENHIP_SCAN_PICK");
+    const bool band = n_seg_eff >= kSubSegs && (uint64_t)a.kept_count * 125ull >= (uint64_t)a.sample_count;  // >= 0.8 % kept
+    const bool super_kernel = a.kept_idx != nullptr && sc.max_super_count <= kGatherMaxSegCodes && (eu ? atoi(eu) != 0 : band);
     if (super_kernel) {
         void (*k3)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t) = a.variant_idx ? gt_scan_gather3_kernel<true> : gt_scan_gather3_kernel<false>;
         const uint32_t n_super = (n_seg_eff + kSubSegs - 1u) / kSubSegs;
@@ -752,12 +588,10 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hi
         hipLaunchKernelGGL(k3, dim3((uint32_t)(groups * n_super)), dim3(kThreads), 0, stream, a, sc, n_seg_eff, n_super, (uint32_t)groups);
         return hipGetLastError();
     }
-    const char *ep = getenv("PGENHIP_SCAN_PICK");  // A/B: 0 = per-lane ctz compaction for medium densities as well
-    const bool pick_kernel = !batch_kernel && a.kept_idx != nullptr && sc.max_seg_count <= kPickMaxSegCodes && (ep ? atoi(ep) != 0 : true);
+    const bool pick_kernel = a.kept_idx != nullptr && sc.max_seg_count <= kPickMaxSegCodes && (ep ? atoi(ep) != 0 : true);
+    const bool dense = (uint64_t)a.kept_count * 4ull > (uint64_t)a.sample_count * 3ull;  // > 75 % kept
     void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t);
-    if (batch_kernel)
-        kern = a.variant_idx ? gt_scan_gather_kernel<true> : gt_scan_gather_kernel<false>;
-    else if (pick_kernel)
+    if (pick_kernel)
         kern = a.variant_idx ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
     else if (a.variant_idx)
         kern = dense ? gt_scan_kernel<true, true> : gt_scan_kernel<true, false>;

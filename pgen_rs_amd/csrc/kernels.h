@@ -51,7 +51,7 @@ constexpr uint32_t kScanSegmentSamples = 16384u;
 struct ScanArgs {
     const uint64_t *keep_words;  // device; n_segments * (kScanSegmentSamples / 64) words
     const uint32_t *seg_rank;    // device; n_segments + 1 entries
-    uint32_t max_seg_count;      // most kept samples in any one segment (picks the gather kernel)
+    uint32_t max_seg_count;      // most kept samples in any one segment
     uint32_t max_super_count;    // most kept samples in any aligned triple of segments (picks the three-segment gather kernel)
 };
 hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hipStream_t stream);

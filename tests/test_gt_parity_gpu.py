@@ -189,14 +189,15 @@ def test_subset_with_strides_offsets_and_gather():
         assert (got == exp).all(), f"kernel {kern}"
 
 
-@pytest.mark.parametrize("batch", ["1", "0"])
+@pytest.mark.parametrize("batch", ["super", "pick", "ctz"])
 def test_scan_kernels_many_rows_per_wave(monkeypatch, batch):
     """Sparse-keep scan kernels with many rows per wave: the gather kernel's code ring is reused
     across batches (12 rows each), rows end mid-triple, segments with no kept sample at the front
     and at the back (the last segment then only owes the '\n'), a locally dense mask (falls back
     to the per-row kernel) and a gapped variant list."""
     monkeypatch.setenv("PGENHIP_SCAN_BLOCKS_PER_CU", "1")  # few blocks -> ~15-25 rows per wave
-    monkeypatch.setenv("PGENHIP_SCAN_BATCH", batch)
+    monkeypatch.setenv("PGENHIP_SCAN_SUPER", "1" if batch == "super" else "0")  # three-segment gather where its ring allows
+    monkeypatch.setenv("PGENHIP_SCAN_PICK", "0" if batch == "ctz" else "1")     # else segment pick / per-lane ctz kernel
     n = 40000  # three 16 384-sample segments, the last one partial
     r = oracle.variant_record_size(n)
     rng = np.random.default_rng(77)
@@ -487,15 +488,16 @@ def test_config3_full_size_100k_by_500k():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("batch", ["1", "0"])
+@pytest.mark.parametrize("batch", ["super", "pick", "ctz"])
 def test_config5_geometry_100k_by_500k_keep_1pct(monkeypatch, batch):
     """BASELINE config 5's per-GPU geometry in ONE launch: 100 000 variants x 500 000 samples
     (12.5 GB of records, offsets beyond 2^32), the 1 % splitmix keep mask of SURVEY 8(d)
-    (4 940 kept -> 19 761-byte rows, 1.98 GB of text).  Gather kernel (batch=1) and per-row scan
-    kernel (batch=0): LF / TAB / slash columns over the whole buffer, byte equality with the
+    (4 940 kept -> 19 761-byte rows, 1.98 GB of text).  Three-segment gather, segment pick and
+    per-lane ctz kernels: LF / TAB / slash columns over the whole buffer, byte equality with the
     oracle on rows from the start, the reference's u32-wrap boundary, the middle and the end,
     and equality of the two kernels' whole outputs through a checksum of checksums."""
-    monkeypatch.setenv("PGENHIP_SCAN_BATCH", batch)
+    monkeypatch.setenv("PGENHIP_SCAN_SUPER", "1" if batch == "super" else "0")
+    monkeypatch.setenv("PGENHIP_SCAN_PICK", "0" if batch == "ctz" else "1")
     n, v = 500_000, 100_000
     free, _total = torch.cuda.mem_get_info(0)
     if free < v * 125_000 + (8 << 30):
@@ -522,7 +524,7 @@ def test_config5_geometry_100k_by_500k_keep_1pct(monkeypatch, batch):
         del body, out, recs, sums
     torch.cuda.empty_cache()
     seen = _CONFIG5_DIGEST.setdefault("digest", digest)
-    assert seen == digest, "gather and per-row scan kernels disagree somewhere in the 1.98 GB of text"
+    assert seen == digest, "the subset kernels disagree somewhere in the 1.98 GB of text"
 
 
 _CONFIG5_DIGEST = {}
