@@ -286,10 +286,10 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;  // `--include-sam` that keeps everybody: same bytes, the all-samples kernels
             if (ctx->subset && !ctx->identity) {
-                // measured crossover (profiles/r01_kernel_sweeps.md, probe17: scan wins at 1 % kept, the gather at 0.1 %): with very sparse masks on long
-                // records the list gather touches only the kept samples' lines and wins; everywhere else the
-                // scan + LDS-compaction kernel does (it reads each record once with wide loads)
-                const bool very_sparse = ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 128ull <= ctx->sample_count;
+                // measured crossover (profiles/r01_kernel_sweeps.md, probe13: N = 500 000, 0.2 % kept list gather 1.13 ms vs 1.49 ms,
+                // 0.4 % kept 1.51 vs 1.47): below ~1/300 kept on long records the list gather touches only the kept
+                // samples' lines and wins; everywhere else the scan-family kernels do (they read each record once, wide)
+                const bool very_sparse = ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 300ull <= ctx->sample_count;
                 if (gt_pick_applicable(a)) {
                     // short records (the 1000 Genomes shape with a sample filter): output-driven pick, any density
                     HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
@@ -372,7 +372,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
                 HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
                 HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             } else if (a.kept_idx != nullptr && ctx->record_size >= 16u &&
-                       !(ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 128ull <= ctx->sample_count)) {
+                       !(ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 300ull <= ctx->sample_count)) {
                 // kept subset: the scan-family kernels write each GT segment behind its prefix, the prefix kernel the rest
                 ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
                 HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
