@@ -304,6 +304,10 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
                 // interleaved A/B puts the two within 1-2 % (profiles/r01_kernel_sweeps.md, probe9), so the simpler
                 // row-item kernel stays the default and this one is opt-in
                 HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream));
+            else if (gt_pick_applicable(a) && ctx->sample_count >= 400u && ctx->sample_count < 1400u)
+                // short rows (1.6-5.6 KiB of text): batches of rows as one run (gt_pick.hip with the identity for a table) beat both
+                // the flat kernel (N = 1000: 0.50 -> 0.58 of roofline) and the stream kernel's one-row work items (N = 1024: 0.49 -> 0.57)
+                HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
             else if (gt_wide_applicable(a))
                 HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
             else if (gt_flat_applicable(a))
@@ -322,7 +326,7 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
             return PGENHIP_OK;
         }
         case PGENHIP_KERNEL_PICK:
-            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "pick kernel needs a kept-sample list with K >= 4, 61 <= N <= 4096 and out_stride == 4K+1");
+            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "pick kernel needs K >= 4, 61 <= N <= 4096 and out_stride == 4K+1");
             HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_SPAN:
@@ -396,7 +400,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             return PGENHIP_OK;
         }
         case PGENHIP_KERNEL_PICK:
-            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_PICK needs a kept-sample list with K >= 4 and 61 <= N <= 4096");
+            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_PICK needs K >= 4 and 61 <= N <= 4096");
             HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
             HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;

@@ -57,25 +57,39 @@ __device__ __forceinline__ void split_offset(uint32_t o, const PickParams &p, ui
 
 // 2-bit code of kept sample `rank` of staged row `row`.  `idx` points at table entry 0; the table has kPadBefore
 // entries of slack in front and kPadAfter behind (ranks -4 .. K+4 occur next to a row's ends: their bytes are
-// never stored), so no clamp is needed.
+// never stored), so no clamp is needed.  IDENT (all samples kept): rank r IS sample r, no table.
 constexpr uint32_t kPadBefore = 4, kPadAfter = 12;
+template <bool IDENT>
 __device__ __forceinline__ uint32_t pick_code(const uint8_t *row, const uint16_t *idx, int32_t rank, uint32_t K)
 {
     (void)K;
-    const uint32_t s = idx[rank];
+    const uint32_t s = IDENT ? (uint32_t)max(rank, 0) : (uint32_t)idx[rank];
     return ((uint32_t)row[s >> 2] >> ((s & 3u) * 2u)) & 3u;
 }
 
 // 16 text bytes of staged row `row` starting at row byte q (q may be negative: the bytes before the row are don't-care)
+template <bool IDENT>
 __device__ __forceinline__ u32x4 pick_text16(const uint8_t *row, const uint16_t *idx, int32_t q, uint32_t K)
 {
+    if (IDENT) {
+        // consecutive samples: one 16-bit window of the record holds the five codes (as in the stream kernel)
+        uint32_t window;
+        if (q >= 0) {
+            uint16_t h;
+            __builtin_memcpy(&h, row + (q >> 4), 2);
+            window = h;
+        } else {
+            window = (uint32_t)row[0] << 8;  // record byte -1 (none) and byte 0
+        }
+        return gt_text16_from_window(window, (int64_t)q);
+    }
     const int32_t g = q >> 2;  // floor
     const uint32_t sh = (uint32_t)q & 3u;
-    const uint32_t t0 = gt_text(pick_code(row, idx, g, K));
-    const uint32_t t1 = gt_text(pick_code(row, idx, g + 1, K));
-    const uint32_t t2 = gt_text(pick_code(row, idx, g + 2, K));
-    const uint32_t t3 = gt_text(pick_code(row, idx, g + 3, K));
-    const uint32_t t4 = gt_text(pick_code(row, idx, g + 4, K));
+    const uint32_t t0 = gt_text(pick_code<false>(row, idx, g, K));
+    const uint32_t t1 = gt_text(pick_code<false>(row, idx, g + 1, K));
+    const uint32_t t2 = gt_text(pick_code<false>(row, idx, g + 2, K));
+    const uint32_t t3 = gt_text(pick_code<false>(row, idx, g + 3, K));
+    const uint32_t t4 = gt_text(pick_code<false>(row, idx, g + 4, K));
     u32x4 v;
     v.x = funnel_bytes(t0, t1, sh);
     v.y = funnel_bytes(t1, t2, sh);
@@ -84,7 +98,7 @@ __device__ __forceinline__ u32x4 pick_text16(const uint8_t *row, const uint16_t 
     return v;
 }
 
-template <bool HAS_VIDX, bool LINES>
+template <bool HAS_VIDX, bool LINES, bool IDENT>
 __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParams p)
 {
     __shared__ uint16_t s_tab[kPadBefore + kMaxSamples + kPadAfter];
@@ -94,8 +108,10 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t K = a.kept_count;
-    for (uint32_t r = tid; r < kPadBefore + K + kPadAfter; r += (uint32_t)kThreads)
-        s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? (uint16_t)a.kept_idx[r - kPadBefore] : (uint16_t)0;
+    if (!IDENT) {
+        for (uint32_t r = tid; r < kPadBefore + K + kPadAfter; r += (uint32_t)kThreads)
+            s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? (uint16_t)a.kept_idx[r - kPadBefore] : (uint16_t)0;
+    }
     __syncthreads();
     const uint16_t *const s_idx = s_tab + kPadBefore;
 
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
             for (uint32_t i = 0; i < rows_here; i++) {
                 const uint8_t *row = stage + i * p.pitch;
                 const uint16_t *idx = s_idx;
-                flush_codes([row, idx, K](uint32_t r) { return pick_code(row, idx, (int32_t)r, K); }, 0u, row_text(a, row0 + i), 0ull,
+                flush_codes([row, idx, K](uint32_t r) { return pick_code<IDENT>(row, idx, (int32_t)r, K); }, 0u, row_text(a, row0 + i), 0ull,
                             (uint64_t)S, 0u, K, lane);
             }
             if (!more) break;
@@ -181,12 +197,12 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
             uint32_t i, pos;
             split_offset(o, p, i, pos);
             const uint8_t *row = stage + i * p.pitch;
-            u32x4 v = pick_text16(row, s_idx, (int32_t)pos, K);
+            u32x4 v = pick_text16<IDENT>(row, s_idx, (int32_t)pos, K);
             const uint32_t nl = S - 1u - pos;                   // chunk byte of this row's '\n' if < 16
             if (nl < 16u) {
                 // the chunk holds '\n' at byte nl and the head of the next row behind it (a whole chunk never ends the run)
                 u32x4 y = {0u, 0u, 0u, 0u};
-                if (nl < 15u) y = pick_text16(row + p.pitch, s_idx, -(int32_t)nl - 1, K);
+                if (nl < 15u) y = pick_text16<IDENT>(row + p.pitch, s_idx, -(int32_t)nl - 1, K);
                 uint32_t xs[4] = {v.x, v.y, v.z, v.w};
                 uint32_t ys[4] = {y.x, y.y, y.z, y.w};
                 uint32_t os[4];
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
             if (on) {
                 uint32_t i, pos;
                 split_offset(o, p, i, pos);
-                const uint32_t code = pick_code(stage + i * p.pitch, s_idx, (int32_t)(pos >> 2), K);
+                const uint32_t code = pick_code<IDENT>(stage + i * p.pitch, s_idx, (int32_t)(pos >> 2), K);
                 run[o] = (uint8_t)(pos == S - 1u ? 0x0Au : gt_text_byte(code, pos & 3u));
             }
         }
@@ -228,7 +244,8 @@ bool gt_pick_applicable(const EmitArgs &a)
 {
     // kept subset, record of one tile (16 <= R <= 1024), rows of >= 17 bytes (a 16-B chunk then touches at most two
     // rows), dense output pitch or full-line mode (rows then go out one by one behind their prefixes)
-    return a.kept_idx != nullptr && a.sample_count <= kMaxSamples && a.record_size >= 16u && a.kept_count >= 4u &&
+    // (kept_idx == NULL: all samples kept — the same kernel with the identity in place of the table)
+    return a.sample_count <= kMaxSamples && a.record_size >= 16u && a.kept_count >= 4u &&
            (a.line_off != nullptr || a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull);
 }
 
@@ -251,10 +268,15 @@ hipError_t launch_gt_pick(const EmitArgs &a, int num_cus, hipStream_t stream)
     p.magic = (uint32_t)(0x100000000ull / p.row_bytes) + 1u;    // exact up to one compare for run offsets < 12 * 16 385 < 2^20
     p.n_batches = (uint32_t)(((uint64_t)a.n_variants + b - 1u) / b);
     void (*kern)(EmitArgs, PickParams);
-    if (a.line_off)
-        kern = a.variant_idx ? gt_pick_kernel<true, true> : gt_pick_kernel<false, true>;
+    if (a.kept_idx == nullptr) {
+        if (a.line_off)
+            kern = a.variant_idx ? gt_pick_kernel<true, true, true> : gt_pick_kernel<false, true, true>;
+        else
+            kern = a.variant_idx ? gt_pick_kernel<true, false, true> : gt_pick_kernel<false, false, true>;
+    } else if (a.line_off)
+        kern = a.variant_idx ? gt_pick_kernel<true, true, false> : gt_pick_kernel<false, true, false>;
     else
-        kern = a.variant_idx ? gt_pick_kernel<true, false> : gt_pick_kernel<false, false>;
+        kern = a.variant_idx ? gt_pick_kernel<true, false, false> : gt_pick_kernel<false, false, false>;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     const uint64_t need = ((uint64_t)p.n_batches + kWaves - 1ull) / kWaves;

@@ -32,8 +32,8 @@ def kernels_for(subset: bool, dense: bool, n: int = 0, k: int = 0):
         ks.append(_capi.KERNEL_SPAN)
     if subset and n >= 61:  # the scan kernel needs records of >= 16 bytes
         ks.append(_capi.KERNEL_SCAN)
-    if subset and dense and 61 <= n <= 4096 and k >= 4:
-        ks.append(_capi.KERNEL_PICK)
+    if dense and 61 <= n <= 4096 and (k >= 4 if subset else True):
+        ks.append(_capi.KERNEL_PICK)  # short records: kept subset through the table, or all samples (identity)
     return ks
 
 
@@ -306,13 +306,17 @@ def test_emit_lines_vs_oracle(n, kept_mod):
     assert (got[want.size :] == SENTINEL).all()
 
 
-@pytest.mark.parametrize("n,v", [(1024, 37), (2504, 700), (4099, 300), (70001, 40)])
-@pytest.mark.parametrize("kernel", [_capi.KERNEL_ROWS, _capi.KERNEL_WIDE])
+@pytest.mark.parametrize("n,v", [(61, 50), (300, 900), (1023, 120), (1024, 37), (2504, 700), (4099, 300), (70001, 40)])
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_ROWS, _capi.KERNEL_WIDE, _capi.KERNEL_PICK, _capi.KERNEL_AUTO])
 def test_emit_lines_stream_kernel(n, v, kernel):
     """Full lines through the work-queue stream kernel (PGENHIP_KERNEL_WIDE) and the general kernel:
     prefixes of 0..40 bytes (so GT segments start at every byte phase and neighbouring lines share
     16-byte chunks), an unaligned output pointer, a gapped variant list, several spans per row
     (N = 70 001), many rows per block; sentinel bytes around the output must stay untouched."""
+    if kernel == _capi.KERNEL_WIDE and n < 1024:
+        pytest.skip("stream kernel: N >= 1024")
+    if kernel == _capi.KERNEL_PICK and n > 4096:
+        pytest.skip("pick kernel: short records only")
     rng = np.random.default_rng(500 + n)
     r = oracle.variant_record_size(n)
     v_file = v + 11
