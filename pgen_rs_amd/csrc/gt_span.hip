@@ -28,6 +28,7 @@ constexpr uint32_t kSpanChunks = 1024;        // 16 stores x 64 lanes
 constexpr uint32_t kMaxPieces = 3;
 constexpr uint32_t kSlabBytes = 1216;         // <= 1024 + 3 x (15 + 16 + 1) staged bytes, 16-B pieces (76 x 16)
 constexpr uint32_t kSlabExtra = 16;           // +0: first record byte of the row after the span's last row
+constexpr uint32_t kExtSlots = kSlabBytes / 16u - 64u;  // 12 staged 16-B slots beyond the first 64 of a span
 constexpr uint32_t kDescBytes = 128;
 constexpr int kRingSlots = 3;
 constexpr int kDescSlots = kRingSlots + 1;
@@ -359,7 +360,7 @@ __device__ __forceinline__ void emit_span(const EmitArgs &a, const SpanParams &p
 }
 
 template <bool HAS_VIDX, bool NT>
-__global__ __launch_bounds__(kThreads) void gt_span_kernel(EmitArgs a, SpanParams p)
+__global__ __launch_bounds__(kThreads, 8) void gt_span_kernel(EmitArgs a, SpanParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t slabs[kNS][kRingSlots][kSlabBytes + kSlabExtra];
     __shared__ __attribute__((aligned(16))) uint8_t s_desc[kNS][kDescSlots][kDescBytes];
@@ -397,7 +398,14 @@ __global__ __launch_bounds__(kThreads) void gt_span_kernel(EmitArgs a, SpanParam
             }
             const uint64_t t_end = t0 == kNoItem ? 0ull : min(t0 + kNS, min(((uint64_t)range + 1ull) * per_range, p.n_items));
             const uint32_t slot = (uint32_t)(step % kRingSlots);
-            v4u in0[kNS], in1[kNS];
+            // in0[w]: slots 0-63 of span w.  Slots 64-75 of ALL spans share two register quads: lane group g = lane / 12
+            // holds the extra slots of span g in ext_a (spans 0-3) and of span 4 + g in ext_b (spans 4-6), fetched by ONE
+            // load each after the span loop (per-span in1 registers cost 28 VGPRs and a block of occupancy)
+            v4u in0[kNS];
+            v4u ext_a = v4u{0u, 0u, 0u, 0u}, ext_b = v4u{0u, 0u, 0u, 0u};
+            const uint8_t *ext_a_addr = a.records, *ext_b_addr = a.records;
+            bool ext_a_on = false, ext_b_on = false;
+            const uint32_t ext_group = lane / kExtSlots, ext_e = lane - ext_group * kExtSlots;
             uint32_t nb[kNS];
             uint64_t row_hint = kNoHint;  // one 64-bit division per claim; the following spans continue where the last ended
 #pragma unroll
@@ -405,7 +413,6 @@ __global__ __launch_bounds__(kThreads) void gt_span_kernel(EmitArgs a, SpanParam
                 const uint64_t t = t0 == kNoItem ? kNoItem : t0 + (uint64_t)w;
                 nb[w] = 0u;
                 in0[w] = v4u{0u, 0u, 0u, 0u};
-                in1[w] = v4u{0u, 0u, 0u, 0u};
                 const bool have = t0 != kNoItem && t < t_end;
                 const uint64_t tag = t0 == kNoItem ? kNoItem - 1ull : (have ? t : kNoItem);
                 if (!have) {
@@ -422,12 +429,18 @@ __global__ __launch_bounds__(kThreads) void gt_span_kernel(EmitArgs a, SpanParam
                         const uint32_t c0 = q == 0u ? ld.cum[0] : (q == 1u ? ld.cum[1] : ld.cum[2]);
                         if (s < ld.cum[kMaxPieces]) in0[w] = *reinterpret_cast<const v4u *>(src + (s - c0) * 16u);
                     }
-                    {
-                        const uint32_t s = lane + 64u;
+                    if (ext_group == (uint32_t)(w < 4 ? w : w - 4)) {
+                        const uint32_t s = ext_e + 64u;
                         const uint32_t q = (s >= ld.cum[1] ? 1u : 0u) + (s >= ld.cum[2] ? 1u : 0u);
                         const uint8_t *src = q == 0u ? ld.src[0] : (q == 1u ? ld.src[1] : ld.src[2]);
                         const uint32_t c0 = q == 0u ? ld.cum[0] : (q == 1u ? ld.cum[1] : ld.cum[2]);
-                        if (s < ld.cum[kMaxPieces]) in1[w] = *reinterpret_cast<const v4u *>(src + (s - c0) * 16u);
+                        if (w < 4) {
+                            ext_a_addr = src + (s - c0) * 16u;
+                            ext_a_on = s < ld.cum[kMaxPieces];
+                        } else {
+                            ext_b_addr = src + (s - c0) * 16u;
+                            ext_b_on = s < ld.cum[kMaxPieces];
+                        }
                     }
                     // the span's last chunk may hold its last row's '\n': then the head of the NEXT row (not staged) is needed
                     const uint32_t lp_tail = pick(sp.n_pieces - 1u, sp.p0.tail, sp.p1.tail, sp.p2.tail);
@@ -438,6 +451,8 @@ __global__ __launch_bounds__(kThreads) void gt_span_kernel(EmitArgs a, SpanParam
                     row_hint = last_row + (lp_tail != kNone ? 1ull : 0ull);
                 }
             }
+            if (ext_a_on) ext_a = *reinterpret_cast<const v4u *>(ext_a_addr);
+            if (ext_b_on) ext_b = *reinterpret_cast<const v4u *>(ext_b_addr);
 #pragma unroll
             for (int w = 0; w < kNS; w++) {
                 if (step >= (uint64_t)kRingSlots) {
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void gt_span_kernel(EmitArgs a, SpanParam
                 }
                 uint8_t *slab = slabs[w][slot];
                 *reinterpret_cast<v4u *>(slab + lane * 16u) = in0[w];
-                if (lane < (kSlabBytes / 16u) - 64u) *reinterpret_cast<v4u *>(slab + (lane + 64u) * 16u) = in1[w];
+                if (ext_group == (uint32_t)(w < 4 ? w : w - 4) && lane < 5u * kExtSlots) *reinterpret_cast<v4u *>(slab + (ext_e + 64u) * 16u) = w < 4 ? ext_a : ext_b;
                 if (lane == 0u) slab[kSlabBytes] = (uint8_t)nb[w];
                 if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), (uint32_t)step + 1u);
             }
@@ -492,14 +507,17 @@ hipError_t launch_gt_span(const EmitArgs &a, int num_cus, hipStream_t stream)
     const char *en = getenv("PGENHIP_WIDE_NT");
     const bool nt = en ? atoi(en) != 0 : true;
     const char *eb = getenv("PGENHIP_WIDE_BLOCKS_PER_CU");
-    const uint64_t cap = (uint64_t)num_cus * (uint64_t)(eb ? atoi(eb) : 3);
+    void (*k)(EmitArgs, SpanParams);
+    if (a.variant_idx) k = nt ? gt_span_kernel<true, true> : gt_span_kernel<true, false>;
+    else k = nt ? gt_span_kernel<false, true> : gt_span_kernel<false, false>;
+    int per_cu = 0;  // exactly the resident blocks: later ones would find the queue empty
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (eb && atoi(eb) > 0) per_cu = atoi(eb);
+    const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
     const uint64_t need = (p.n_items + kNS - 1ull) / kNS;
     const uint32_t grid = (uint32_t)(need < cap ? need : cap);
     hipError_t me = hipMemsetAsync(a.work_counters, 0, 8u * 128u, stream);
     if (me != hipSuccess) return me;
-    void (*k)(EmitArgs, SpanParams);
-    if (a.variant_idx) k = nt ? gt_span_kernel<true, true> : gt_span_kernel<true, false>;
-    else k = nt ? gt_span_kernel<false, true> : gt_span_kernel<false, false>;
     hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), 0, stream, a, p);
     return hipGetLastError();
 }
