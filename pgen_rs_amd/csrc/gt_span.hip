@@ -373,6 +373,8 @@ __global__ __launch_bounds__(kThreads, 8) void gt_span_kernel(EmitArgs a, SpanPa
         (&s_done[0][0])[threadIdx.x] = 0u;
     }
     __syncthreads();
+    // the other set of queue heads is zeroed for the next work-queue launch of this ctx (stream-ordered behind this one)
+    if (blockIdx.x == 0u && threadIdx.x < 8u && a.work_counters_next) a.work_counters_next[threadIdx.x * 16u] = 0ull;
     constexpr uint64_t kNoItem = ~0ull;
 
     if (wave == 0u) {
@@ -516,8 +518,6 @@ hipError_t launch_gt_span(const EmitArgs &a, int num_cus, hipStream_t stream)
     const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
     const uint64_t need = (p.n_items + kNS - 1ull) / kNS;
     const uint32_t grid = (uint32_t)(need < cap ? need : cap);
-    hipError_t me = hipMemsetAsync(a.work_counters, 0, 8u * 128u, stream);
-    if (me != hipSuccess) return me;
     hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), 0, stream, a, p);
     return hipGetLastError();
 }

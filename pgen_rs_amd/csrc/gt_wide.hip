@@ -511,6 +511,8 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
         (&s_done[0][0])[threadIdx.x] = 0u;
     }
     __syncthreads();
+    // the other set of queue heads is zeroed for the next work-queue launch of this ctx (stream-ordered behind this one)
+    if (blockIdx.x == 0u && threadIdx.x < 8u && a.work_counters_next) a.work_counters_next[threadIdx.x * 16u] = 0ull;
     constexpr uint64_t kNoItem = ~0ull;
 
     if (wave == 0u) {
@@ -711,8 +713,6 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
     const char *ed = getenv("PGENHIP_WIDE_DYN");
     const bool dyn = ed ? atoi(ed) != 0 : true;  // work queue on by default (interleaved A/B: +9 % on the chr22 block)
     if ((stream_ns == 7 && dyn && a.work_counters) || a.line_off) {
-        hipError_t me = hipMemsetAsync(a.work_counters, 0, 8u * 128u, stream);
-        if (me != hipSuccess) return me;
         const uint64_t need = (p.n_items + 6ull) / 7ull;
         void (*dk)(EmitArgs, WideParams);
         if (a.line_off) {
@@ -739,6 +739,9 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
         if (a.line_off) return launch_copy_prefixes(a, num_cus, stream);  // the prefixes: disjoint bytes, same stream, any order
         return hipGetLastError();
     }
+    // A/B-only kernels below do not use the queue: keep the ctx's alternating head sets consistent (the set handed to
+    // this launch stays clean, the other one is zeroed here instead of by the kernel)
+    if (a.work_counters_next) (void)hipMemsetAsync(a.work_counters_next, 0, 8u * 128u, stream);
     if (stream_ns == 3 || stream_ns == 7) {
         const uint64_t need = (p.n_items + (uint64_t)stream_ns - 1ull) / (uint64_t)stream_ns;
         const uint64_t cap = (uint64_t)num_cus * (uint64_t)blocks_per_cu;

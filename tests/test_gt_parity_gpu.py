@@ -270,6 +270,30 @@ def test_pick_kernel_short_records(n):
                 raise AssertionError(f"n={n} mask={label} v={v} off={out_offset}: {bad.size} bytes differ, first at {bad[:6]}")
 
 
+def test_work_queue_heads_alternate_across_launches(monkeypatch):
+    """One context, many launches: the work-queue kernels claim from one set of queue heads and zero the
+    other for the launch after them.  Interleave work-queue launches with launches of kernels that
+    do not use the queue (and with the A/B kernels) and check every output."""
+    n, v = 2504, 3001
+    rng = np.random.default_rng(4242)
+    r = oracle.variant_record_size(n)
+    recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
+    want = oracle.decode_emit(recs, v, n).tobytes()
+    with pgen_rs_amd.GtEngine(n, device=0) as eng:
+        d_recs = torch.from_numpy(recs).to(DEV)
+        plan = [_capi.KERNEL_WIDE, _capi.KERNEL_WIDE, _capi.KERNEL_ROWS, _capi.KERNEL_WIDE, _capi.KERNEL_SPAN, _capi.KERNEL_FLAT,
+                _capi.KERNEL_SPAN, _capi.KERNEL_WIDE, _capi.KERNEL_PICK, _capi.KERNEL_WIDE, _capi.KERNEL_WIDE]
+        for step, kern in enumerate(plan):
+            if step == 5:
+                monkeypatch.setenv("PGENHIP_WIDE_DYN", "0")   # static partition for a while: the queue is not used
+            if step == 8:
+                monkeypatch.delenv("PGENHIP_WIDE_DYN")
+            out = torch.full((v * (4 * n + 1),), SENTINEL, dtype=torch.uint8, device=DEV)
+            eng.decode_emit(d_recs, v, out=out, kernel=kern)
+            eng.wait()
+            assert out.cpu().numpy().tobytes() == want, f"launch {step} (kernel {kern})"
+
+
 def test_single_variant_and_zero_variants():
     n = 90
     recs = np.arange(oracle.variant_record_size(n), dtype=np.uint8)
