@@ -47,6 +47,7 @@ struct WideParams {
     uint64_t n_items;        // V * spans_per_row
     uint32_t spans_per_row;
     uint32_t head;           // out address & 127: the chunk grid is anchored at a 128-B line boundary
+    uint32_t n_ranges;       // work-queue kernel: contiguous item ranges with a head word each (1, 2, 4 or 8)
     uint64_t *dbg;           // diagnostic builds only (PGENHIP_DEBUG_TIMES=1): per-wave {start, end, items} stamps, else nullptr
 };
 
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, Wi
 // gt_stream_dyn_kernel — gt_stream_kernel with a WORK QUEUE instead of a static item partition.
 // Only ~3 of these 512-thread blocks fit on a CU, so a static grid-stride split of a big grid runs
 // in rounds and the last, partly filled round is a tail of several hundred microseconds on a
-// 2.4 ms launch (measured with per-wave s_memrealtime stamps).  Here the items are cut into 8
-// contiguous ranges (one per XCD, picked by blockIdx & 7 — placement is a speed hint only); the
+// 2.4 ms launch (measured with per-wave s_memrealtime stamps).  Here the items are cut into
+// contiguous ranges (two by default — one per XCD measured 1 % slower; picked by blockIdx & (n - 1)); the
 // loader wave claims NS consecutive items per step with one returning atomicAdd on its range's
 // head word (heads live 128 B apart; ~10 claims/us per word, far below the ~88/us a word takes)
 // and steals from the next range when its own is drained.  Every block therefore runs until the
@@ -517,8 +518,9 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
 
     if (wave == 0u) {
         // ------------------------------ loader wave ------------------------------
-        const uint64_t per_range = (p.n_items + 7ull) / 8ull;
-        uint32_t range = blockIdx.x & 7u;
+        const uint32_t nr = p.n_ranges;  // power of two <= 8
+        const uint64_t per_range = (p.n_items + (uint64_t)nr - 1ull) / (uint64_t)nr;
+        uint32_t range = blockIdx.x & (nr - 1u);
         uint32_t drained = 0u;  // consecutive ranges found empty
         // The claim for step s+1 is ISSUED right after step s's record loads and only read at the top of step
         // s+1, so the atomic's round trip (1-2 us under load) hides behind the load latency instead of adding
@@ -533,16 +535,16 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             // ---- resolve the claim issued one step ago (lane 0 asked, the wave shares the answer)
             uint64_t t0 = kNoItem;
             uint64_t got = sgpr64(pending);
-            while (drained < 8u) {
+            while (drained < nr) {
                 const uint64_t lo = (uint64_t)range * per_range;
                 const uint64_t hi = min(lo + per_range, p.n_items);
                 if (lo + got < hi) {
                     t0 = lo + got;
                     break;
                 }
-                range = (range + 1u) & 7u;  // own range drained: steal from the next one
+                range = (range + 1u) & (nr - 1u);  // own range drained: steal from the next one
                 drained++;
-                if (drained < 8u) got = sgpr64(issue_claim(range));
+                if (drained < nr) got = sgpr64(issue_claim(range));
             }
             const uint64_t t_end = t0 == kNoItem ? 0ull : min(t0 + NS, min(((uint64_t)range + 1ull) * per_range, p.n_items));
             const uint32_t slot = (uint32_t)(step % kRingSlots);
@@ -698,6 +700,12 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
     p.total_bytes = (uint64_t)a.n_variants * p.row_bytes;
     p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 127ull);
     p.dbg = nullptr;
+    {
+        // interleaved in one process (tools/probes/gpu_probe15.py, chr22 block): 8 ranges 2.058 ms, 4: 2.045, 2: 2.038, 1: 2.039
+        const char *er = getenv("PGENHIP_WIDE_RANGES");  // A/B: 1, 2, 4 or 8 item ranges (8 = one per XCD)
+        const int nr = er ? atoi(er) : 2;
+        p.n_ranges = nr == 1 || nr == 4 || nr == 8 ? (uint32_t)nr : 2u;
+    }
     // a row owns floor(S/16) or ceil(S/16) chunks (one more for row 0 with an unaligned pointer), and
     // its first span starts up to 63 chunks before them (1-KiB-aligned span grid)
     const uint64_t max_row_chunks = (p.row_bytes + 15ull) / 16ull + 1ull + 63ull;
