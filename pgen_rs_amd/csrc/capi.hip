@@ -23,7 +23,6 @@ struct pgenhip_ctx {
     uint32_t record_size = 0;
     uint32_t kept_count = 0;
     bool subset = false;
-    uint32_t work_epoch = 0;           // which set of work-queue heads the next launch uses
     bool identity = false;             // a kept list that names every sample: AUTO takes the all-samples kernels
     uint32_t *d_kept = nullptr;
     uint64_t *d_keep_words = nullptr;  // scan kernel: keep bitmap, zero-padded to whole segments
@@ -170,8 +169,8 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
         ctx->stream = ctx->own_stream;
         if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) { rc = fail_hip(e, "hipEventCreate"); break; }
         if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) { rc = fail_hip(e, "hipEventCreate"); break; }
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_work), 2u * 8u * 128u)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(work counters)"); break; }
-        if ((e = hipMemset(ctx->d_work, 0, 2u * 8u * 128u)) != hipSuccess) { rc = fail_hip(e, "hipMemset(work counters)"); break; }
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_work), 9u * 128u)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(work counters)"); break; }
+        if ((e = hipMemset(ctx->d_work, 0, 9u * 128u)) != hipSuccess) { rc = fail_hip(e, "hipMemset(work counters)"); break; }  // the kernels leave them zero
         if (ctx->subset) {
             size_t bytes = (size_t)(kept_count ? kept_count : 1u) * sizeof(uint32_t);
             if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_kept), bytes)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(kept_idx)"); break; }
@@ -265,18 +264,8 @@ static int fill_args(pgenhip_ctx *ctx, EmitArgs &a, const void *d_records, uint6
     a.prefix_off = nullptr;
     a.line_off = nullptr;
     a.max_line_bytes = 0;
-    a.work_counters = ctx->d_work;  // non-NULL: the work-queue kernels are applicable; take_queue() picks the set per launch
-    a.work_counters_next = nullptr;
+    a.work_counters = ctx->d_work;
     return PGENHIP_OK;
-}
-
-// Two sets of queue heads: a work-queue launch claims from one and zeroes the other for the work-queue launch after it
-// (launches of one ctx are stream-ordered), so no memset node is needed per launch.  Called right before such a launch.
-static void take_queue(pgenhip_ctx *ctx, EmitArgs &a)
-{
-    a.work_counters = ctx->d_work + (ctx->work_epoch & 1u) * (8u * 16u);
-    a.work_counters_next = ctx->d_work + ((ctx->work_epoch + 1u) & 1u) * (8u * 16u);
-    ctx->work_epoch++;
 }
 
 int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
@@ -315,13 +304,13 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
                 // stream-span kernel: 10 % fewer store instructions than the row-item kernel but more scalar work;
                 // interleaved A/B puts the two within 1-2 % (profiles/r01_kernel_sweeps.md, probe9), so the simpler
                 // row-item kernel stays the default and this one is opt-in
-                { take_queue(ctx, a); HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream)); }
+                HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream));
             else if (gt_pick_applicable(a) && ctx->sample_count >= 400u && ctx->sample_count < 1400u)
                 // short rows (1.6-5.6 KiB of text): batches of rows as one run (gt_pick.hip with the identity for a table) beat both
                 // the flat kernel (N = 1000: 0.50 -> 0.58 of roofline) and the stream kernel's one-row work items (N = 1024: 0.49 -> 0.57)
                 HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
             else if (gt_wide_applicable(a))
-                { take_queue(ctx, a); HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream)); }
+                HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
             else if (gt_flat_applicable(a))
                 HIP_TRY(launch_gt_flat(a, ctx->num_cus, ctx->stream));
             else
@@ -343,11 +332,11 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
             return PGENHIP_OK;
         case PGENHIP_KERNEL_SPAN:
             if (!gt_span_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "span kernel needs all samples kept, N >= 2048 and out_stride == 4N+1");
-            { take_queue(ctx, a); HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream)); }
+            HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_WIDE:
             if (!gt_wide_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "wide kernel needs all samples kept, N >= 1024 and out_stride == 4N+1");
-            { take_queue(ctx, a); HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream)); }
+            HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_FLAT:
             if (!gt_flat_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "flat kernel needs all samples kept and out_stride == 4N+1");
@@ -382,7 +371,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             // all samples kept and rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place
             // behind their prefixes (+ a small prefix copy); otherwise the general kernel assembles whole lines
             if (gt_wide_lines_applicable(a)) {
-                { take_queue(ctx, a); HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream)); }
+                HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
             } else if (gt_pick_applicable(a)) {
                 // kept subset on short records: the pick kernel flushes each parked row behind its prefix
                 HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
@@ -402,7 +391,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             return PGENHIP_OK;
         case PGENHIP_KERNEL_WIDE:
             if (!gt_wide_lines_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_WIDE needs all samples kept and sample_count >= 1024");
-            { take_queue(ctx, a); HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream)); }
+            HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_SCAN: {
             if (!ctx->subset || ctx->record_size < 16u) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_SCAN needs a kept-sample list and N >= 61");

@@ -373,8 +373,6 @@ __global__ __launch_bounds__(kThreads, 8) void gt_span_kernel(EmitArgs a, SpanPa
         (&s_done[0][0])[threadIdx.x] = 0u;
     }
     __syncthreads();
-    // the other set of queue heads is zeroed for the next work-queue launch of this ctx (stream-ordered behind this one)
-    if (blockIdx.x == 0u && threadIdx.x < 8u && a.work_counters_next) a.work_counters_next[threadIdx.x * 16u] = 0ull;
     constexpr uint64_t kNoItem = ~0ull;
 
     if (wave == 0u) {
@@ -468,6 +466,16 @@ __global__ __launch_bounds__(kThreads, 8) void gt_span_kernel(EmitArgs a, SpanPa
                 if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), (uint32_t)step + 1u);
             }
             if (t0 == kNoItem) break;
+        }
+        // ---- self-cleaning queue: the last loader wave to leave re-zeroes the heads for the next launch (every block's
+        // claims precede its exit count; no memset node in front of the kernel, and a captured graph can be replayed)
+        if (lane == 0u) {
+            unsigned long long *const exits = reinterpret_cast<unsigned long long *>(a.work_counters + 8u * 16u);
+            if (atomicAdd(exits, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+#pragma unroll
+                for (uint32_t h = 0; h < 8u; h++) atomicExch(reinterpret_cast<unsigned long long *>(a.work_counters + h * 16u), 0ull);
+                atomicExch(exits, 0ull);
+            }
         }
     } else {
         // ------------------------------ storer waves -----------------------------

@@ -512,8 +512,6 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
         (&s_done[0][0])[threadIdx.x] = 0u;
     }
     __syncthreads();
-    // the other set of queue heads is zeroed for the next work-queue launch of this ctx (stream-ordered behind this one)
-    if (blockIdx.x == 0u && threadIdx.x < 8u && a.work_counters_next) a.work_counters_next[threadIdx.x * 16u] = 0ull;
     constexpr uint64_t kNoItem = ~0ull;
 
     if (wave == 0u) {
@@ -626,6 +624,16 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                 if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), step + 1u);
             }
             if (t0 == kNoItem) break;
+        }
+        // ---- self-cleaning queue: the last loader wave to leave re-zeroes the heads for the next launch (every block's
+        // claims precede its exit count; no memset node in front of the kernel, and a captured graph can be replayed)
+        if (lane == 0u) {
+            unsigned long long *const exits = reinterpret_cast<unsigned long long *>(a.work_counters + 8u * 16u);
+            if (atomicAdd(exits, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+#pragma unroll
+                for (uint32_t h = 0; h < 8u; h++) atomicExch(reinterpret_cast<unsigned long long *>(a.work_counters + h * 16u), 0ull);
+                atomicExch(exits, 0ull);
+            }
         }
     } else {
         // ------------------------------ storer waves -----------------------------
@@ -748,9 +756,6 @@ hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
         if (a.line_off) return launch_copy_prefixes(a, num_cus, stream);  // the prefixes: disjoint bytes, same stream, any order
         return hipGetLastError();
     }
-    // A/B-only kernels below do not use the queue: keep the ctx's alternating head sets consistent (the set handed to
-    // this launch stays clean, the other one is zeroed here instead of by the kernel)
-    if (a.work_counters_next) (void)hipMemsetAsync(a.work_counters_next, 0, 8u * 128u, stream);
     if (stream_ns == 3 || stream_ns == 7) {
         const uint64_t need = (p.n_items + (uint64_t)stream_ns - 1ull) / (uint64_t)stream_ns;
         const uint64_t cap = (uint64_t)num_cus * (uint64_t)blocks_per_cu;

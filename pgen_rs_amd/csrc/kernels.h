@@ -22,8 +22,7 @@ struct EmitArgs {
     const uint64_t *prefix_off;
     const uint64_t *line_off;
     uint64_t max_line_bytes;      // upper bound of any line's byte length (prefix + 4K + 1)
-    uint64_t *work_counters;      // device scratch owned by the ctx: 8 x 128-B-spaced work-queue heads (the set this launch claims from)
-    uint64_t *work_counters_next;   // the OTHER set of heads: the work-queue kernels zero it for the next launch (no memset node)
+    uint64_t *work_counters;      // device scratch owned by the ctx: 8 x 128-B-spaced work-queue heads + a block-exit counter at +1024 B; zero between launches (the last block out re-zeroes them)
 };
 
 // General row-tiled kernel: any alignment, any strides, list gather for kept subsets.

@@ -271,9 +271,9 @@ def test_pick_kernel_short_records(n):
 
 
 def test_work_queue_heads_alternate_across_launches(monkeypatch):
-    """One context, many launches: the work-queue kernels claim from one set of queue heads and zero the
-    other for the launch after them.  Interleave work-queue launches with launches of kernels that
-    do not use the queue (and with the A/B kernels) and check every output."""
+    """One context, many launches: the last block of a work-queue launch re-zeroes the queue heads.
+    Interleave work-queue launches with launches of kernels that do not use the queue (and with the
+    A/B kernels) and check every output."""
     n, v = 2504, 3001
     rng = np.random.default_rng(4242)
     r = oracle.variant_record_size(n)
@@ -292,6 +292,39 @@ def test_work_queue_heads_alternate_across_launches(monkeypatch):
             eng.decode_emit(d_recs, v, out=out, kernel=kern)
             eng.wait()
             assert out.cpu().numpy().tobytes() == want, f"launch {step} (kernel {kern})"
+
+
+@pytest.mark.parametrize("n,kept_frac", [(2504, None), (2504, 0.3), (40000, 0.01), (700, None)])
+def test_hip_graph_capture_and_replay(n, kept_frac):
+    """include/pgen_hip.h promises: no allocation, no synchronisation inside pgenhip_decode_emit, so a call
+    can be captured into a HIP graph.  Capture one call (work-queue stream kernel, pick and scan-family kernels), replay it on three different record blocks, compare with the oracle."""
+    rng = np.random.default_rng(31 + n)
+    v = 257
+    r = oracle.variant_record_size(n)
+    kept = None if kept_frac is None else np.sort(rng.choice(n, size=int(n * kept_frac), replace=False)).astype(np.uint32)
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        d_recs = torch.zeros(v * r, dtype=torch.uint8, device=DEV)
+        out = torch.full((v * eng.gt_row_bytes,), SENTINEL, dtype=torch.uint8, device=DEV)
+        side = torch.cuda.Stream(device=DEV)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eng.use_torch_stream()
+            eng.decode_emit(d_recs, v, out=out)  # warm-up outside the capture (module load, occupancy query)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            eng.use_torch_stream()                 # bind the ctx to the capturing stream
+            eng.decode_emit(d_recs, v, out=out)
+        for rep in range(3):
+            recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
+            d_recs.copy_(torch.from_numpy(recs))
+            out.fill_(SENTINEL)
+            g.replay()
+            torch.cuda.synchronize()
+            want = oracle.decode_emit(recs, v, n, kept_idx=kept)
+            assert out.cpu().numpy().tobytes() == want.tobytes(), f"replay {rep}"
+        eng.use_torch_stream()
 
 
 def test_single_variant_and_zero_variants():
