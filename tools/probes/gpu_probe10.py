@@ -16,10 +16,11 @@ def main(n=2504, v=1_103_547, rounds=5):
         blob = torch.full((int(prefix_off[-1]),), 65, dtype=torch.uint8, device="cuda:0")
         d_poff = torch.from_numpy(prefix_off).to("cuda:0"); d_loff = torch.from_numpy(line_off).to("cuda:0")
         out = torch.empty(int(line_off[-1]) + 64, dtype=torch.uint8, device="cuda:0")
+        max_prefix = int(plen.max())  # host-side preparation stays outside the timed region
         ts = []
         for r in range(rounds + 1):
             eng.timer_start()
-            eng.emit_lines(recs, v, blob, d_poff, d_loff, int(plen.max()), out)
+            eng.emit_lines(recs, v, blob, d_poff, d_loff, max_prefix, out)
             ms = eng.timer_stop()
             if r: ts.append(ms)
         tot = int(line_off[-1]) + v * eng.record_size + int(prefix_off[-1])
