@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — the GT decode/emit hot path on MI355X, measured the way BASELINE.json asks.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W                      # BASELINE configs[2]: 100 000 x 500 000, K = N
+    python bench.py --config {c3,chr22,c4,c5,c4shard,c5shard,basic2}   # the other named shapes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W         # BASELINE configs[3]: 1 M x 500 000, variant-sharded
 
-A "step" = one pass of the hot path (src/pfile.rs:165-190) over one variant block of synthetic
-.pgen records that are already resident in HBM.  Workload = BASELINE.json configs[1], the
-chr22 shape (1 103 547 variants x 2 504 samples, all samples kept): 0.69 GB of packed 2-bit
-records in, 11.05 GB of GT text out per step and per GPU.  Variant blocks shard with no
-collective: with N GPUs every rank decodes its own block of that shape (weak
-scaling), and `value` is total genotypes / max-over-ranks time.
+A config names a TOTAL workload (V variants x N samples, a keep rule).  Its kept-variant list is cut into
+`world` contiguous ranges by `pgen_rs_amd.sharding.shard_range` (the reference's outer loop,
+src/pfile.rs:156, iterated in file order) and rank r decodes range r — strong scaling, no collective on the
+data path.  A "step" = one pass of the hot path (src/pfile.rs:165-190) over the rank's whole
+range: the range's mode-0x02 records are resident in HBM before the timed region starts; the GT text goes to
+an output buffer in HBM that holds as many variants as fit beside the records (one launch per step when the
+whole range fits — configs[2] does: 12.5 GB in, 200 GB out — otherwise a few launches that re-use the buffer,
+as a D2H pipeline would).
 
-One JSON line on stdout (rank 0).  Extra objects: `roofline` (HBM, algorithmic bytes
-R + 4K + 1 per variant / hipEvent time on the kernel's stream) and `cpu_baseline` (the oracle's
-literal restatement of the reference loop, 1 core, bounded sample, rank 0 at N=1 only).
+One JSON line on stdout (rank 0).  Besides the contract's keys:
+  `roofline`       HBM; algorithmic bytes (R + 4K + 1 per variant) / hipEvent time on the
+                   kernel's stream; per-step event pairs give min / median / max (the output buffer's
+                   physical placement moves a launch by 5-9 % between processes);
+                   `traffic` from the committed PMC passes of the same shape (profiles/r02_*/pmc_summary.json)
+  `cpu_baseline`   the oracle's literal restatement of the reference loop, 1 core, same N, bounded V
+  `host_delivered` PCIe-inclusive rate (pinned host records -> H2D || kernel || D2H -> pinned host text),
+                   measured OUTSIDE the timed region; it is never `value`
+  `self_check`     structure of every row + a torch re-encode round trip on sampled rows (no oracle here)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -28,24 +38,42 @@ from pathlib import Path
 REPO_ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO_ROOT))
 
-CHR22_VARIANTS = 1_103_547
-CHR22_SAMPLES = 2_504
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PCIE_PEAK_GBS = 63.0    # PCIe Gen5 x16 per GPU (MI355X_MICROARCH.md)
 SEED_DATA = 0x5047454E
 
+# name -> (total variants, samples, keep modulus (0 = all samples kept), what it is)
+CONFIGS = {
+    "c3": (100_000, 500_000, 0, "BASELINE.json configs[2]: synthetic 100k variants x 500k samples, all variants all samples"),
+    "chr22": (1_103_547, 2_504, 0, "BASELINE.json configs[1]: 1000G chr22 shape, all variants all samples"),
+    "c4": (1_000_000, 500_000, 0, "BASELINE.json configs[3]: synthetic 1M variants x 500k samples, variant-sharded"),
+    "c5": (1_000_000, 500_000, 100, "BASELINE.json configs[4]: synthetic 1M x 500k with the 1% sample-keep mask, variant-sharded"),
+    "c4shard": (125_000, 500_000, 0, "one GPU's 1/8 shard of BASELINE.json configs[3] (125k variants x 500k samples)"),
+    "c5shard": (125_000, 500_000, 100, "one GPU's 1/8 shard of BASELINE.json configs[4] (125k x 500k, 1% sample-keep mask)"),
+    "basic2": (200_000, 300, 0, "the reference's own dataset shape (data/basic2, data/random1/info.txt: 200k variants x 300 samples)"),
+}
 
-def cpu_baseline(sample_variants: int, n_samples: int, target_s: float = 12.0) -> dict:
+
+def cpu_baseline(n_samples: int, kept, target_s: float = 12.0) -> dict:
     """Times the oracle's file-to-file literal restatement of src/pfile.rs:149-192 on one core.
 
-    oracle/ is test infrastructure: it is used here only as the timed CPU baseline, never on
-    the measured GPU path.  The reference itself is Rust and cannot be built in this image.
+    oracle/ is test infrastructure: it is used here only as the timed CPU baseline, never on the measured
+    GPU path.  The reference itself is Rust and cannot be built in this image.  Same N and keep list as the
+    GPU workload; V is cut so the VCF body on tmpfs stays <= ~1.5 GB per pass.
     """
     sys.path.insert(0, str(REPO_ROOT / "oracle"))
+    import numpy as np
     import pgen_oracle as oracle  # noqa: E402
 
+    k = n_samples if kept is None else int(len(kept))
+    r = oracle.variant_record_size(n_samples)
+    row = 4 * k + 1
+    # cost is ~ per kept genotype + per record byte read: bound both the output and the input
+    sample_variants = int(max(64, min(200_000, 1.5e9 // row, 1.0e9 // max(r, 1))))
     shm = Path("/dev/shm") if Path("/dev/shm").is_dir() else Path("/tmp")
     pgen = shm / f"pgenhip_bench_{os.getpid()}.pgen"
     out = shm / f"pgenhip_bench_{os.getpid()}.vcfbody"
+    outs = []
     try:
         recs = oracle.synth_records(n_samples, sample_variants, 0, SEED_DATA)
         header = bytes([0x6C, 0x1B, 0x02]) + sample_variants.to_bytes(4, "little") + n_samples.to_bytes(4, "little") + b"\x40"
@@ -53,39 +81,28 @@ def cpu_baseline(sample_variants: int, n_samples: int, target_s: float = 12.0) -
             f.write(header)
             f.write(recs.tobytes())
         del recs
-        # repeat the bounded sample until ~target_s of CPU work has been timed (output truncated each pass)
         passes, dt = 0, 0.0
         while dt < target_s and passes < 64:
             t0 = time.perf_counter()
-            rc = oracle.output_vcf_body_file(str(pgen), n_samples, str(out), n_var=sample_variants)
+            rc = oracle.output_vcf_body_file(str(pgen), n_samples, str(out), n_var=sample_variants, kept_idx=kept)
             dt += time.perf_counter() - t0
             passes += 1
             if rc != 0:
                 raise RuntimeError(f"oracle baseline failed: {rc}")
         out_bytes = out.stat().st_size
-        assert out_bytes == sample_variants * (4 * n_samples + 1)
-    except BaseException:
-        for p in (pgen, out):
-            try:
-                p.unlink()
-            except FileNotFoundError:
-                pass
-        raise
-    out.unlink()
-    # the same loop on all host cores (variant ranges -> separate files): NOT the reference's behaviour
-    # (pgen-rs is single-threaded), reported beside it as BASELINE.md asks
-    import numpy as np
-    from concurrent.futures import ThreadPoolExecutor
+        assert out_bytes == sample_variants * row
+        out.unlink()
+        # the same loop on all host cores (variant ranges -> separate files): NOT the reference's behaviour
+        # (pgen-rs is single-threaded), reported beside it as BASELINE.md asks
+        from concurrent.futures import ThreadPoolExecutor
 
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    all_cores = None
-    try:
+        cores = max(1, min(os.cpu_count() or 1, 64))
         bounds = [sample_variants * i // cores for i in range(cores + 1)]
         idx = [np.arange(bounds[i], bounds[i + 1], dtype=np.uint32) for i in range(cores)]
         outs = [shm / f"pgenhip_bench_{os.getpid()}_{i}.vcfbody" for i in range(cores)]
 
         def one(i):  # ctypes releases the GIL for the duration of the C call
-            return oracle.output_vcf_body_file(str(pgen), n_samples, str(outs[i]), var_idx=idx[i])
+            return oracle.output_vcf_body_file(str(pgen), n_samples, str(outs[i]), var_idx=idx[i], kept_idx=kept)
 
         reps, t_all = 0, 0.0
         with ThreadPoolExecutor(max_workers=cores) as ex:
@@ -96,43 +113,154 @@ def cpu_baseline(sample_variants: int, n_samples: int, target_s: float = 12.0) -
                 reps += 1
                 if any(rcs):
                     raise RuntimeError(f"oracle baseline failed: {rcs}")
-        all_cores = {"value": reps * sample_variants * n_samples / t_all, "unit": "genotypes/s", "cores": cores,
-                     "seconds": t_all, "note": "same C loop, variant ranges on all host cores, one output file per thread; not the reference's behaviour"}
+        all_cores = {"value": reps * sample_variants * n_samples / t_all, "unit": "genotypes/s", "cores": cores, "seconds": t_all,
+                     "note": "same C loop, variant ranges on all host cores, one output file per thread; not the reference's behaviour"}
     finally:
-        for o in list(locals().get("outs", [])):
+        for p in [pgen, out, *outs]:
             try:
-                o.unlink()
+                p.unlink()
             except FileNotFoundError:
                 pass
-    try:
-        pgen.unlink()
-    except FileNotFoundError:
-        pass
     return {
-        "all_cores": all_cores,
         "value": passes * sample_variants * n_samples / dt,
         "unit": "genotypes/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {sample_variants} variants x {n_samples} samples of the same synthetic workload x {passes} passes, "
+        "sample": f"first {sample_variants} variants x {n_samples} samples ({k} kept) of the same synthetic workload x {passes} passes, "
                   f".pgen and VCF body on tmpfs, C restatement of src/pfile.rs:149-192 "
                   f"(per-variant alloc+seek+read, two 8-KiB-BufWriter writes per genotype), {dt:.2f} s",
         "seconds": dt,
         "vcf_MB_per_s": passes * out_bytes / dt / 1e6,
         "host_cores_available": os.cpu_count(),
+        "all_cores": all_cores,
     }
+
+
+def host_delivered(torch, pgen_rs_amd, dev_index: int, n: int, kept, v_avail: int, target_out_bytes: float = 12e9) -> dict:
+    """PCIe-inclusive rate of the same path (src/pfile.rs:149-190 without the file system): records start in
+    pinned host memory, blocks go H2D -> pgenhip_decode_emit -> D2H into a pinned host ring on two streams
+    with one ctx each (what host/pfile.cpp does around its pread/pwrite).  Run OUTSIDE the timed region."""
+    dev = torch.device("cuda", dev_index)
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=dev_index) as e0, pgen_rs_amd.GtEngine(n, kept_idx=kept, device=dev_index) as e1:
+        engs = (e0, e1)
+        r, row = e0.record_size, e0.gt_row_bytes
+        per_variant = r + row
+        block = int(max(1, min(65_536, (256 << 20) // per_variant)))   # ~256 MiB over the link per block
+        v = int(max(block, min(v_avail, target_out_bytes // per_variant)))
+        v = min(v, v_avail)
+        n_blocks = (v + block - 1) // block
+        h_recs = torch.empty(v * r, dtype=torch.uint8).pin_memory()
+        h_recs.copy_(e0.synth_records(v, seed=SEED_DATA)[: v * r].cpu())
+        ring = 4
+        h_out = [torch.empty(block * row, dtype=torch.uint8).pin_memory() for _ in range(ring)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        d_recs = [torch.empty(block * r, dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_out = [torch.empty(block * row, dtype=torch.uint8, device=dev) for _ in range(2)]
+        for s, e in zip(streams, engs):
+            with torch.cuda.stream(s):
+                e.use_torch_stream()  # binds the ctx to torch's current stream = s
+
+        def run():
+            for i in range(n_blocks):
+                b0 = i * block
+                nb = min(block, v - b0)
+                k2 = i & 1  # stream, device buffers; ring slot i % 4 is re-used by the same stream two blocks later (stream-ordered)
+                with torch.cuda.stream(streams[k2]):
+                    d_recs[k2][: nb * r].copy_(h_recs[b0 * r : (b0 + nb) * r], non_blocking=True)
+                    engs[k2].decode_emit(d_recs[k2], nb, out=d_out[k2])
+                    h_out[i % ring][: nb * row].copy_(d_out[k2][: nb * row], non_blocking=True)
+            torch.cuda.synchronize(dev)
+
+        run()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run()
+            ts.append(time.perf_counter() - t0)
+        t = min(ts)
+        last = h_out[(n_blocks - 1) % ring]
+        ok = True
+        if row > 1:
+            ok = int(last[0]) == 9 and int(last[2]) == 47
+        nb_last = v - (n_blocks - 1) * block
+        ok = ok and int(last[nb_last * row - 1]) == 10
+        if not ok:
+            raise RuntimeError("host_delivered: malformed GT text came back over the link")
+        for e in engs:
+            e.use_own_stream()
+        return {
+            "genotypes_per_s": v * n / t,
+            "vcf_MB_per_s": v * row / t / 1e6,
+            "d2h_GBps": v * row / t / 1e9,
+            "h2d_GBps": v * r / t / 1e9,
+            "link_GBps_both_ways": v * per_variant / t / 1e9,
+            "pcie_peak_GBps": PCIE_PEAK_GBS,
+            "d2h_frac_of_pcie": v * row / t / 1e9 / PCIE_PEAK_GBS,
+            "seconds": t,
+            "sample": f"{v} variants x {n} samples in blocks of {block} variants, 2 streams x (H2D, kernel, D2H), pinned host records and a "
+                      f"{ring}-slot pinned text ring, best of 3 passes; file I/O excluded (the CLI adds pread/pwrite around the same pipeline)",
+        }
+
+
+def self_check(torch, recs, out, v_rows: int, n: int, r: int, k: int, kept, row_bytes: int) -> dict:
+    """Parity of what the timed launches left in HBM, without the oracle: (1) every row's '\\n', first TAB and
+    first '/' (strided over the whole buffer); (2) on sampled rows a re-encode round trip — text bytes 1 and 3
+    of every genotype -> 2-bit code, compared with the codes torch unpacks from the record bits
+    (src/pfile.rs:172-183 read backwards).  Full byte parity against the oracle is tests/'s job."""
+    dev = out.device
+    rows2d = out[: v_rows * row_bytes].view(v_rows, row_bytes)
+    bad = int((rows2d[:, row_bytes - 1] != 10).sum())
+    if k > 0:
+        bad += int((rows2d[:, 0] != 9).sum()) + int((rows2d[:, 2] != 47).sum())
+    sample_rows = sorted({0, v_rows - 1, *[(v_rows * i) // 61 for i in range(61)]})
+    kept_t = None
+    if kept is not None:
+        kept_t = torch.as_tensor(kept.astype("int64"), device=dev)
+    mismatches = 0
+    for j in sample_rows:
+        text = rows2d[j, : 4 * k].view(k, 4).to(torch.int32) if k else None
+        if k == 0:
+            continue
+        a, b = text[:, 1], text[:, 3]
+        # "0/0" -> 0, "0/1" -> 1, "1/1" -> 2, "./." -> 3
+        code_text = torch.where(a == 46, torch.full_like(a, 3), (a - 48) + (b - 48))
+        wellformed = ((text[:, 0] == 9) & (text[:, 2] == 47) & (((a == 46) & (b == 46)) | ((a >= 48) & (a <= 49) & (b >= 48) & (b <= 49) & (a <= b)))).all()
+        rec = recs[j * r : (j + 1) * r].to(torch.int32)
+        s = kept_t if kept_t is not None else torch.arange(n, device=dev)
+        code_rec = (rec[s // 4] >> ((s % 4) * 2)) & 3
+        mismatches += int((code_text != code_rec).sum()) + (0 if bool(wellformed) else 1)
+    if bad or mismatches:
+        raise RuntimeError(f"bench self-check failed: {bad} malformed row ends, {mismatches} genotype mismatches")
+    return {"rows_structure_checked": v_rows, "rows_reencoded": len(sample_rows), "genotypes_reencoded": len(sample_rows) * k, "ok": True}
+
+
+def load_traffic(v_launch: int, n: int, k: int):
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    runs, KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md) — only if the shape matches exactly."""
+    for p in sorted((REPO_ROOT / "profiles").glob("r02_*/pmc_summary.json")):
+        try:
+            t = json.loads(p.read_text())
+        except (OSError, ValueError):
+            continue
+        sh = t.get("shape", {})
+        if sh.get("variants_per_launch") == v_launch and sh.get("samples") == n and sh.get("kept") == k and t.get("hbm_bytes_per_launch"):
+            return t["hbm_bytes_per_launch"], f"{p.relative_to(REPO_ROOT)}: {t.get('note', '')}"
+    return None, None
 
 
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--variants", type=int, default=CHR22_VARIANTS, help="variants per GPU per step")
-    ap.add_argument("--samples", type=int, default=CHR22_SAMPLES)
-    ap.add_argument("--keep-modulus", type=int, default=0, help="keep sample i iff splitmix64(seed^i) %% m == 0 (0 = all)")
-    ap.add_argument("--cpu-sample-variants", type=int, default=200_000)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="named workload (default: c3 on one GPU, c4 = 1M x 500k variant-sharded on several)")
+    ap.add_argument("--variants", type=int, default=None, help="custom TOTAL variants (overrides the config's)")
+    ap.add_argument("--samples", type=int, default=None, help="custom sample count (overrides the config's)")
+    ap.add_argument("--keep-modulus", type=int, default=None, help="keep sample i iff splitmix64(seed^i) %% m == 0 (0 = all)")
+    ap.add_argument("--max-launch-variants", type=int, default=0, help="cap on variants per launch (0 = as many as fit in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-delivered", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --dist-backend gloo) so the N>1 code path can run on a 1-GPU box")
@@ -143,6 +271,7 @@ def main() -> int:
     import torch.distributed as dist
 
     import pgen_rs_amd
+    from pgen_rs_amd.sharding import shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -165,32 +294,60 @@ def main() -> int:
         else:
             dist.init_process_group(backend=args.dist_backend)
 
-    n, v = args.samples, args.variants
+    cfg_name = args.config or ("c3" if world == 1 else "c4")
+    v_total, n, keep_mod, cfg_desc = CONFIGS[cfg_name]
+    custom = False
+    if args.variants is not None and args.variants != v_total:
+        v_total, custom = args.variants, True
+    if args.samples is not None and args.samples != n:
+        n, custom = args.samples, True
+    if args.keep_modulus is not None and args.keep_modulus != keep_mod:
+        keep_mod, custom = args.keep_modulus, True
+
     kept = None
-    if args.keep_modulus:
+    if keep_mod:
         from pgen_rs_amd.synth import keep_indices
 
-        kept = keep_indices(n, modulus=args.keep_modulus)
+        kept = keep_indices(n, modulus=keep_mod)
 
     eng = pgen_rs_amd.GtEngine(n, kept_idx=kept, device=local_rank)
-    k = eng.kept_count
-    # every rank owns a distinct block of variants of the same shape (weak scaling, no collective)
-    recs = eng.synth_records(v, first_variant=rank * v, seed=SEED_DATA)
-    out = torch.empty(v * eng.gt_row_bytes, dtype=torch.uint8, device=dev)
+    k, r, row_bytes = eng.kept_count, eng.record_size, eng.gt_row_bytes
+    begin, end = shard_range(v_total, world, rank)  # this rank's contiguous slice of the kept-variant list
+    v = end - begin
+
+    # the rank's records, resident before the timed region; then as many output rows as fit beside them
+    recs = eng.synth_records(v, first_variant=begin, seed=SEED_DATA)
+    torch.cuda.synchronize(dev)
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    share = world if args.all_ranks_on_device0 else 1
+    budget = max(free_b // share - (6 << 30), row_bytes)
+    v_launch = max(1, min(v, budget // row_bytes)) if v else 0
+    if args.max_launch_variants:
+        v_launch = min(v_launch, args.max_launch_variants)
+    n_launch = (v + v_launch - 1) // v_launch if v else 0
+    if n_launch:
+        v_launch = (v + n_launch - 1) // n_launch  # even launches
+    out = torch.empty(max(v_launch, 1) * row_bytes, dtype=torch.uint8, device=dev)
 
     def step() -> None:
-        eng.decode_emit(recs, v, out=out, kernel=args.kernel)
+        for b0 in range(0, v, v_launch):
+            nb = min(v_launch, v - b0)
+            eng.decode_emit(recs, nb, out=out, kernel=args.kernel, records_offset=b0 * r)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
+    # per-step event pairs on the stream the kernels run on (the ctx is bound to torch's current stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    eng.timer_start()                      # hipEvent on the stream the kernels run on
-    for _ in range(args.steps):
+    eng.timer_start()                      # hipEvent pair of the ctx, same stream, around the whole timed region
+    for e0, e1 in evs:
+        e0.record()
         step()
+        e1.record()
     event_ms = eng.timer_stop()            # records + synchronises the stop event
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -198,29 +355,33 @@ def main() -> int:
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
 
-    t_all = torch.tensor([dt, event_ms], dtype=torch.float64, device=red_dev)
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    t_all = torch.tensor([dt, event_ms, max(step_ms), -min(step_ms)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     dt_max, event_ms_max = float(t_all[0]), float(t_all[1])
 
-    # spot check on rank 0: the last row is well formed (TAB a / b ... LF); full parity is tests/'s job
-    if rank == 0 and v > 0 and k > 0:
-        tail = out[(v - 1) * eng.gt_row_bytes :][: eng.gt_row_bytes].cpu()
-        assert int(tail[-1]) == 10 and int(tail[0]) == 9 and int(tail[2]) == 47, "malformed GT row"
+    check = None
+    if rank == 0 and v > 0:
+        last_nb = v - (n_launch - 1) * v_launch  # rows the last launch of a step left in `out`
+        check = self_check(torch, recs[(n_launch - 1) * v_launch * r :], out, last_nb, n, r, k, kept, row_bytes)
 
     if rank == 0:
-        genotypes_per_step = world * v * n                    # every 2-bit code of every record is decoded
-        alg_bytes_per_launch = v * (eng.record_size + 4 * k + 1)  # R + 4K + 1 per variant
-        kernel_ms = event_ms_max / args.steps
-        achieved_gbs = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        traffic_note = None
-        tpath = REPO_ROOT / "profiles" / "r01_hbm_traffic.json"
-        if tpath.exists():
-            t = json.loads(tpath.read_text())
-            if t.get("variants") == v and t.get("samples") == n and t.get("kept") == k:
-                traffic = t.get("hbm_bytes_per_launch")
-                traffic_note = t.get("note")
+        genotypes_per_step = v_total * n                       # every 2-bit code of every record is decoded
+        launches = args.steps * n_launch
+        alg_bytes_per_launch = v_launch * (r + 4 * k + 1)      # R + 4K + 1 per variant
+        alg_bytes_per_step = v * (r + 4 * k + 1)
+        launch_ms = event_ms_max / launches                    # max-over-ranks event time / launches per rank
+        achieved_gbs = alg_bytes_per_step / (event_ms_max / args.steps * 1e-3) / 1e9
+        traffic, traffic_note = load_traffic(v_launch, n, k)
+        shape = f"{v_total} variants x {n} samples, " + ("all samples kept" if kept is None else f"{k} samples kept (splitmix64 mask, 1/{keep_mod})")
+        if custom:
+            workload = f"custom shape ({shape}); derived from preset {cfg_name}"
+        else:
+            workload = f"{cfg_name}: {cfg_desc} ({shape})"
+        workload += (f"; rank r decodes its contiguous 1/{world} of the variants ({v} here)" if world > 1 else "") + \
+                    f"; mode-0x02 records resident in HBM -> VCF GT text in HBM, {n_launch} launch(es) of <= {v_launch} variants per step"
+        med = statistics.median(step_ms)
         line = {
             "metric": "genotypes decoded/sec (variants x samples / s)",
             "value": genotypes_per_step * args.steps / dt_max,
@@ -230,20 +391,24 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"chr22-shape: {v} variants x {n} samples per GPU, {'all samples kept' if kept is None else f'{k} samples kept'}, "
-                            "mode-0x02 records resident in HBM -> VCF GT text in HBM (BASELINE.json configs[1])",
-                "variants_per_gpu": v,
+                "workload": workload,
+                "preset": "custom" if custom else cfg_name,
+                "variants_total": v_total,
+                "variants_this_rank": v,
+                "variants_per_launch": v_launch,
+                "launches_per_step": n_launch,
                 "samples": n,
                 "kept_samples": k,
-                "sharding": f"variant blocks, {world} rank(s), no collective",
+                "sharding": f"contiguous variant ranges, {world} rank(s), no collective",
+                "distribution": "uniform 2-bit codes (splitmix64 counter generator, SURVEY.md §8d)",
             },
-            "vcf_MB_per_s": world * v * (4 * k + 1) * args.steps / dt_max / 1e6,
-            "genotypes_emitted_per_s": world * v * k * args.steps / dt_max,
+            "vcf_MB_per_s": v_total * (4 * k + 1) * args.steps / dt_max / 1e6,
+            "genotypes_emitted_per_s": v_total * k * args.steps / dt_max,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved_gbs,
@@ -253,12 +418,23 @@ def main() -> int:
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "kernel_ms_avg": kernel_ms,
-                "read_only_frac": v * eng.record_size / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernel_ms_avg": launch_ms,
+                "launches_timed": launches,
+                "read_only_frac": v * r / (event_ms_max / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "step_ms": {"min": min(step_ms), "median": med, "max": max(step_ms),
+                            "max_over_ranks": float(t_all[2]), "min_over_ranks": -float(t_all[3])},
+                "frac_step_best": alg_bytes_per_step / (min(step_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_step_median": alg_bytes_per_step / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_step_worst": alg_bytes_per_step / (max(step_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
+            "self_check": check,
         }
+        del out
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_host_delivered:
+            line["host_delivered"] = host_delivered(torch, pgen_rs_amd, local_rank, n, kept, v)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_variants, v), n)
+            line["cpu_baseline"] = cpu_baseline(n, kept)
         print(json.dumps(line), flush=True)
 
     eng.close()

@@ -19,6 +19,21 @@
  *
  * Threading: a ctx is bound to one device and is not thread-safe; use one
  * ctx per device per host thread.  Distinct ctxs are independent.
+ *
+ * Streams: launches are asynchronous on the ctx stream (its own, or the one
+ * given to pgenhip_set_stream).  A ctx may be moved between streams at any
+ * time and launches queued on different streams may overlap: every launch
+ * takes its own block of work-queue counters from a ring of
+ * PGENHIP_LAUNCHES_IN_FLIGHT, so at most that many launches of ONE ctx may be
+ * in flight at once (a host that keeps more queued must pgenhip_wait in
+ * between).  The kernels leave their counter block zeroed; after a launch
+ * that FAILED (any negative status from a launch call) the ctx re-zeroes the
+ * whole ring in stream order before its next launch.  A kernel that faults
+ * on the device takes the process down like any HIP fault; nothing is
+ * recoverable in that case.
+ *
+ * Nothing in this library reads the process environment: launch-shape knobs
+ * are per ctx (pgenhip_tune) and default to the measured best.
  */
 #ifndef PGEN_HIP_H
 #define PGEN_HIP_H
@@ -30,7 +45,8 @@
 extern "C" {
 #endif
 
-#define PGENHIP_ABI_VERSION 1u
+#define PGENHIP_ABI_VERSION 2u
+#define PGENHIP_LAUNCHES_IN_FLIGHT 16u
 
 typedef enum pgenhip_status {
     PGENHIP_OK = 0,
@@ -63,13 +79,24 @@ int pgenhip_parse_header(const uint8_t header[12], uint32_t *variant_count, uint
 /* src/pfile.rs:165  byte offset of record var_idx in the file; computed in u64
  * (the reference multiplies in u32 and wraps at var_idx*R >= 2^32 — SURVEY.md F5). */
 uint64_t pgenhip_record_offset(uint64_t var_idx, uint32_t record_size);
+/* src/pfile.rs:156  the outer loop walks the kept-variant list in file order; a shard is a
+ * contiguous slice of that iteration space.  [*begin, *end) of the n_variants
+ * kept variants owned by `rank` of `world`; sizes differ by at most one, low ranks take the
+ * extra.  The ONE partitioner: the C++ host's device threads, bench.py's ranks and the tests
+ * all call this.  PGENHIP_ERR_BAD_ARG for world == 0 or rank >= world. */
+int pgenhip_shard_range(uint64_t n_variants, uint32_t world, uint32_t rank, uint64_t *begin, uint64_t *end);
 
 /* ---- context ---------------------------------------------------------- */
 /* Binds a device and the kept-sample list (src/pfile.rs:128 sam_idx_rcs; the
  * list filter_metadata :319-333 builds is strictly ascending, and that is
- * required here).  kept_idx == NULL means "all samples" (K = N fast path);
- * otherwise kept_idx is a HOST array of kept_count indices, copied.
- * kept_count may be 0 (every row is then just "\n"). */
+ * required here).  Without PGENHIP_CREATE_KEEP_LIST, kept_idx == NULL means
+ * "all samples" (K = N fast path) and a non-NULL kept_idx is a HOST array of
+ * kept_count indices, copied.  With PGENHIP_CREATE_KEEP_LIST in `flags` the
+ * pair (kept_idx, kept_count) IS the list whatever the pointer: kept_count
+ * may be 0 (every row is then just "\n") and kept_idx may then be NULL — a
+ * host whose filter kept nobody must say so with the flag, not with the
+ * pointer (an empty std::vector's data() is NULL). */
+#define PGENHIP_CREATE_KEEP_LIST 1u
 int pgenhip_create(pgenhip_ctx **ctx, int device_ordinal, uint32_t sample_count,
                    const uint32_t *kept_idx, uint32_t kept_count, uint32_t flags);
 int pgenhip_destroy(pgenhip_ctx *ctx);
@@ -88,10 +115,11 @@ uint64_t pgenhip_gt_row_bytes(const pgenhip_ctx *ctx);
 #define PGENHIP_KERNEL_AUTO 0u
 #define PGENHIP_KERNEL_ROWS 1u   /* general row-tiled kernel (any stride/alignment, list gather) */
 #define PGENHIP_KERNEL_FLAT 2u   /* dense all-samples stream kernel (out_stride == 4N+1) */
-#define PGENHIP_KERNEL_SCAN 3u   /* kept-subset scan + wave ballot/popcount compaction */
+#define PGENHIP_KERNEL_SCAN 3u   /* kept subset on long records: per-segment rank->sample table pick / three-segment gather (N >= 61) */
 #define PGENHIP_KERNEL_WIDE 4u   /* dense all-samples, wide LDS-staged record loads, one row piece per item (N >= 1024) */
-#define PGENHIP_KERNEL_SPAN 5u   /* dense all-samples, 16-KiB stream spans across row ends (N >= 2048) */
+/* 5u was round 1's stream-span kernel (measured level with WIDE, removed) */
 #define PGENHIP_KERNEL_PICK 6u   /* kept subset on short records (61 <= N <= 4096, K >= 4, dense pitch): output-driven pick through the kept list */
+#define PGENHIP_KERNEL_RUNS 7u   /* dense all-samples on SHORT rows (8 <= N <= ~2000, dense records, no gather): runs of rows as one work item */
 #define PGENHIP_KERNEL_MASK 0xFu
 
 /* src/pfile.rs:165-190 for a block of n_variants kept variants.
@@ -122,6 +150,19 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
                        const void *d_prefix_blob, const uint64_t *d_prefix_off,
                        const uint64_t *d_line_off, uint64_t max_prefix_bytes,
                        void *d_out, uint32_t flags);
+
+/* Launch-shape knobs of one ctx (tests force small grids to exercise ring re-use; A/B probes).
+ * value 0 restores the built-in default of a knob unless noted. */
+typedef enum pgenhip_knob {
+    PGENHIP_KNOB_WIDE_BLOCKS_PER_CU = 1, /* stream kernel: resident blocks per CU (default: occupancy API) */
+    PGENHIP_KNOB_WIDE_RANGES = 2,        /* stream kernel: work-queue ranges 1, 2 (default), 4, 8 */
+    PGENHIP_KNOB_FLAT_BLOCKS_PER_CU = 3, /* flat kernel: grid cap per CU (default 64) */
+    PGENHIP_KNOB_SCAN_BLOCKS_PER_CU = 4, /* segment kernels: resident blocks per CU (default: occupancy API) */
+    PGENHIP_KNOB_SCAN_SUPER = 5,         /* three-segment gather kernel: -1 in its measured band (default), 0 never, 1 wherever its ring allows */
+    PGENHIP_KNOB_PICK_BATCH_BYTES = 6,   /* short-record pick kernel: text bytes per batch (default 32768) */
+    PGENHIP_KNOB_RUNS_ROWS = 7           /* RUNS kernel: rows per work item (default: as many as one wide load / one span holds) */
+} pgenhip_knob;
+int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value);
 
 /* Block until everything queued on the ctx stream has finished. */
 int pgenhip_wait(pgenhip_ctx *ctx);

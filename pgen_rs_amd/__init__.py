@@ -10,7 +10,8 @@ from ._capi import (  # noqa: F401
     KERNEL_FLAT,
     KERNEL_ROWS,
     KERNEL_SCAN,
-    KERNEL_SPAN,
+    KERNEL_PICK,
+    KERNEL_RUNS,
     KERNEL_WIDE,
     PgenHipError,
 )
@@ -34,5 +35,6 @@ __all__ = [
     "KERNEL_FLAT",
     "KERNEL_SCAN",
     "KERNEL_WIDE",
-    "KERNEL_SPAN",
+    "KERNEL_PICK",
+    "KERNEL_RUNS",
 ]

@@ -35,9 +35,19 @@ KERNEL_ROWS = 1
 KERNEL_FLAT = 2
 KERNEL_SCAN = 3
 KERNEL_WIDE = 4
-KERNEL_SPAN = 5
 KERNEL_PICK = 6
+KERNEL_RUNS = 7
 SYNTH_DIRTY_PAD = 1
+CREATE_KEEP_LIST = 1
+LAUNCHES_IN_FLIGHT = 16
+
+KNOB_WIDE_BLOCKS_PER_CU = 1
+KNOB_WIDE_RANGES = 2
+KNOB_FLAT_BLOCKS_PER_CU = 3
+KNOB_SCAN_BLOCKS_PER_CU = 4
+KNOB_SCAN_SUPER = 5
+KNOB_PICK_BATCH_BYTES = 6
+KNOB_RUNS_ROWS = 7
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -53,6 +63,7 @@ PROTOTYPES = {
     "pgenhip_variant_record_size": (C.c_uint32, [C.c_uint32]),
     "pgenhip_parse_header": (C.c_int, [C.c_char_p, u32p, u32p]),
     "pgenhip_record_offset": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+    "pgenhip_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]),
     "pgenhip_create": (C.c_int, [C.POINTER(ctx_p), C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
     "pgenhip_destroy": (C.c_int, [ctx_p]),
     "pgenhip_set_stream": (C.c_int, [ctx_p, C.c_void_p]),
@@ -62,6 +73,7 @@ PROTOTYPES = {
     "pgenhip_gt_row_bytes": (C.c_uint64, [ctx_p]),
     "pgenhip_decode_emit": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]),
     "pgenhip_emit_lines": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
+    "pgenhip_tune": (C.c_int, [ctx_p, C.c_uint32, C.c_int32]),
     "pgenhip_wait": (C.c_int, [ctx_p]),
     "pgenhip_timer_start": (C.c_int, [ctx_p]),
     "pgenhip_timer_stop": (C.c_int, [ctx_p, C.POINTER(C.c_float)]),

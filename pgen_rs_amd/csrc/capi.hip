@@ -6,8 +6,6 @@
 #include <algorithm>
 #include <hip/hip_runtime.h>
 
-#include <stdlib.h>
-
 #include <new>
 #include <string>
 #include <vector>
@@ -25,11 +23,13 @@ struct pgenhip_ctx {
     bool subset = false;
     bool identity = false;             // a kept list that names every sample: AUTO takes the all-samples kernels
     uint32_t *d_kept = nullptr;
-    uint64_t *d_keep_words = nullptr;  // scan kernel: keep bitmap, zero-padded to whole segments
-    uint32_t *d_seg_rank = nullptr;    // scan kernel: kept samples before each segment
-    uint32_t max_seg_count = 0;        // scan kernel: most kept samples in one segment
-    uint32_t max_super_count = 0;      // scan kernel: most kept samples in an aligned triple of segments
-    uint64_t *d_work = nullptr;        // stream kernel: per-XCD work-queue heads (8 x 128 B)
+    uint32_t *d_seg_rank = nullptr;    // segment kernels: kept samples before each segment
+    uint32_t max_seg_count = 0;        // segment kernels: most kept samples in one segment
+    uint32_t max_super_count = 0;      // segment kernels: most kept samples in an aligned triple of segments
+    uint64_t *d_work = nullptr;        // stream kernel: ring of PGENHIP_LAUNCHES_IN_FLIGHT counter blocks (8 work-queue heads 128 B apart + an exit counter)
+    uint32_t launch_seq = 0;           // next counter block of the ring
+    bool work_dirty = false;           // a launch failed: counters may be non-zero, re-zero the ring before the next launch
+    Tuning tune;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr;
@@ -65,6 +65,9 @@ int bind(const pgenhip_ctx *ctx)
     HIP_TRY(hipSetDevice(ctx->device));
     return PGENHIP_OK;
 }
+
+constexpr size_t kWorkBlockBytes = 9u * 128u;  // 8 heads 128 B apart + the exit counter
+constexpr size_t kWorkBlockWords = kWorkBlockBytes / sizeof(uint64_t);
 
 }  // namespace
 
@@ -130,12 +133,25 @@ uint64_t pgenhip_record_offset(uint64_t var_idx, uint32_t record_size)
     return 12ull + var_idx * (uint64_t)record_size;
 }
 
+// src/pfile.rs:156: contiguous slices of the kept-variant iteration space
+int pgenhip_shard_range(uint64_t n_variants, uint32_t world, uint32_t rank, uint64_t *begin, uint64_t *end)
+{
+    if (!begin || !end) return fail(PGENHIP_ERR_BAD_ARG, "NULL argument");
+    if (world == 0u || rank >= world) return fail(PGENHIP_ERR_BAD_ARG, "rank outside [0, world)");
+    const uint64_t base = n_variants / world, extra = n_variants % world;
+    *begin = (uint64_t)rank * base + std::min<uint64_t>(rank, extra);
+    *end = *begin + base + (rank < extra ? 1u : 0u);
+    return PGENHIP_OK;
+}
+
 int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
                    const uint32_t *kept_idx, uint32_t kept_count, uint32_t flags)
 {
-    (void)flags;
     if (!out) return fail(PGENHIP_ERR_BAD_ARG, "ctx out-pointer is NULL");
     *out = nullptr;
+    if (flags & ~PGENHIP_CREATE_KEEP_LIST) return fail(PGENHIP_ERR_BAD_ARG, "unknown create flag");
+    const bool subset = (flags & PGENHIP_CREATE_KEEP_LIST) != 0u || kept_idx != nullptr;
+    if (subset && kept_count && !kept_idx) return fail(PGENHIP_ERR_BAD_ARG, "kept_count > 0 with a NULL kept_idx");
     if (sample_count > 0x7FFFFFFFu) return fail(PGENHIP_ERR_TOO_LARGE, "sample_count > 2^31-1");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -144,7 +160,7 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
         return fail(PGENHIP_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
     }
     if (device_ordinal < 0 || device_ordinal >= n) return fail(PGENHIP_ERR_NO_DEVICE, "device ordinal out of range");
-    if (kept_idx) {
+    if (subset) {
         for (uint32_t k = 0; k < kept_count; k++) {
             if (kept_idx[k] >= sample_count) return fail(PGENHIP_ERR_INDEX_RANGE, "kept_idx entry >= sample_count");
             if (k && kept_idx[k] <= kept_idx[k - 1]) return fail(PGENHIP_ERR_BAD_ARG, "kept_idx not strictly ascending");
@@ -155,9 +171,9 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
     ctx->device = device_ordinal;
     ctx->sample_count = sample_count;
     ctx->record_size = pgenhip_variant_record_size(sample_count);
-    ctx->subset = kept_idx != nullptr;
-    ctx->identity = kept_idx != nullptr && kept_count == sample_count;  // strictly ascending and complete = 0..N-1
-    ctx->kept_count = kept_idx ? kept_count : sample_count;
+    ctx->subset = subset;
+    ctx->identity = subset && kept_count == sample_count;  // strictly ascending and complete = 0..N-1
+    ctx->kept_count = subset ? kept_count : sample_count;
 
     int rc = PGENHIP_OK;
     do {
@@ -169,33 +185,26 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
         ctx->stream = ctx->own_stream;
         if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) { rc = fail_hip(e, "hipEventCreate"); break; }
         if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) { rc = fail_hip(e, "hipEventCreate"); break; }
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_work), 9u * 128u)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(work counters)"); break; }
-        if ((e = hipMemset(ctx->d_work, 0, 9u * 128u)) != hipSuccess) { rc = fail_hip(e, "hipMemset(work counters)"); break; }  // the kernels leave them zero
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_work), PGENHIP_LAUNCHES_IN_FLIGHT * kWorkBlockBytes)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(work counters)"); break; }
+        if ((e = hipMemset(ctx->d_work, 0, PGENHIP_LAUNCHES_IN_FLIGHT * kWorkBlockBytes)) != hipSuccess) { rc = fail_hip(e, "hipMemset(work counters)"); break; }  // the kernels leave them zero
         if (ctx->subset) {
             size_t bytes = (size_t)(kept_count ? kept_count : 1u) * sizeof(uint32_t);
             if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_kept), bytes)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(kept_idx)"); break; }
             if (kept_count) {
                 if ((e = hipMemcpy(ctx->d_kept, kept_idx, (size_t)kept_count * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(kept_idx)"); break; }
             }
-            // the same selection as a bitmap + per-segment ranks (what the scan kernel stages in LDS)
+            // kept samples before each 16 384-sample segment (what the segment kernels slice the list by)
             const uint32_t n_seg = (sample_count + kScanSegmentSamples - 1u) / kScanSegmentSamples;
             const uint32_t n_seg_eff = n_seg ? n_seg : 1u;
-            const size_t words_per_seg = kScanSegmentSamples / 64u;
-            std::vector<uint64_t> words((size_t)n_seg_eff * words_per_seg, 0ull);
             std::vector<uint32_t> seg_rank((size_t)n_seg_eff + 1u, 0u);
-            for (uint32_t k = 0; k < kept_count; k++) {
-                words[kept_idx[k] >> 6] |= 1ull << (kept_idx[k] & 63u);
-                seg_rank[(size_t)(kept_idx[k] / kScanSegmentSamples) + 1u]++;
-            }
+            for (uint32_t k = 0; k < kept_count; k++) seg_rank[(size_t)(kept_idx[k] / kScanSegmentSamples) + 1u]++;
             for (uint32_t g = 0; g < n_seg_eff; g++) {
                 ctx->max_seg_count = std::max(ctx->max_seg_count, seg_rank[g + 1u]);
                 seg_rank[g + 1u] += seg_rank[g];
             }
             for (uint32_t g = 0; g < n_seg_eff; g += 3u)
                 ctx->max_super_count = std::max(ctx->max_super_count, seg_rank[std::min(g + 3u, n_seg_eff)] - seg_rank[g]);
-            if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_keep_words), words.size() * sizeof(uint64_t))) != hipSuccess) { rc = fail_hip(e, "hipMalloc(keep bitmap)"); break; }
             if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_seg_rank), seg_rank.size() * sizeof(uint32_t))) != hipSuccess) { rc = fail_hip(e, "hipMalloc(segment ranks)"); break; }
-            if ((e = hipMemcpy(ctx->d_keep_words, words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(keep bitmap)"); break; }
             if ((e = hipMemcpy(ctx->d_seg_rank, seg_rank.data(), seg_rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(segment ranks)"); break; }
         }
     } while (0);
@@ -215,7 +224,6 @@ int pgenhip_destroy(pgenhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->d_kept) (void)hipFree(ctx->d_kept);
-    if (ctx->d_keep_words) (void)hipFree(ctx->d_keep_words);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_seg_rank) (void)hipFree(ctx->d_seg_rank);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
@@ -264,8 +272,38 @@ static int fill_args(pgenhip_ctx *ctx, EmitArgs &a, const void *d_records, uint6
     a.prefix_off = nullptr;
     a.line_off = nullptr;
     a.max_line_bytes = 0;
-    a.work_counters = ctx->d_work;
+    a.work_counters = nullptr;
     return PGENHIP_OK;
+}
+
+// Every launch gets its own counter block from the ring, so launches of one ctx queued on different streams
+// never share work-queue heads (include/pgen_hip.h, "Streams").  After a failed launch the ring is re-zeroed
+// in stream order first.
+static int claim_counters(pgenhip_ctx *ctx, EmitArgs &a)
+{
+    if (ctx->work_dirty) {
+        HIP_TRY(hipMemsetAsync(ctx->d_work, 0, PGENHIP_LAUNCHES_IN_FLIGHT * kWorkBlockBytes, ctx->stream));
+        ctx->work_dirty = false;
+    }
+    a.work_counters = ctx->d_work + (size_t)(ctx->launch_seq++ % PGENHIP_LAUNCHES_IN_FLIGHT) * kWorkBlockWords;
+    return PGENHIP_OK;
+}
+
+#define LAUNCH_TRY(expr)                           \
+    do {                                           \
+        hipError_t e__ = (expr);                   \
+        if (e__ != hipSuccess) {                   \
+            ctx->work_dirty = true;                \
+            return fail_hip(e__, #expr);           \
+        }                                          \
+    } while (0)
+
+// measured crossover (profiles/r01_kernel_sweeps.md: N = 500 000, 0.2 % kept list gather 1.13 ms vs 1.49 ms,
+// 0.4 % kept 1.51 vs 1.47): below ~1/300 kept on long records the list gather touches only the kept
+// samples' lines and wins; everywhere else the segment kernels do (they read each record once, wide)
+static bool very_sparse(const pgenhip_ctx *ctx)
+{
+    return ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 300ull <= ctx->sample_count;
 }
 
 int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
@@ -279,71 +317,62 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
     if (rc) return rc;
     if (n_variants > 1 && out_stride < 4ull * ctx->kept_count + 1ull)
         return fail(PGENHIP_ERR_BAD_ARG, "out_stride < 4K+1");
+    if (flags & ~PGENHIP_KERNEL_MASK) return fail(PGENHIP_ERR_BAD_ARG, "unknown decode_emit flag");
     a.out_stride = out_stride;
     if (n_variants == 0) return PGENHIP_OK;
+    rc = claim_counters(ctx, a);
+    if (rc) return rc;
+    const Tuning &t = ctx->tune;
+    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
 
-    const uint32_t which = flags & PGENHIP_KERNEL_MASK;
-    switch (which) {
+    switch (flags & PGENHIP_KERNEL_MASK) {
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;  // `--include-sam` that keeps everybody: same bytes, the all-samples kernels
-            if (ctx->subset && !ctx->identity) {
-                // measured crossover (profiles/r01_kernel_sweeps.md, probe13: N = 500 000, 0.2 % kept list gather 1.13 ms vs 1.49 ms,
-                // 0.4 % kept 1.51 vs 1.47): below ~1/300 kept on long records the list gather touches only the kept
-                // samples' lines and wins; everywhere else the scan-family kernels do (they read each record once, wide)
-                const bool very_sparse = ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 300ull <= ctx->sample_count;
-                if (gt_pick_applicable(a)) {
+            if (a.kept_idx != nullptr) {
+                if (gt_pick_applicable(a))
                     // short records (the 1000 Genomes shape with a sample filter): output-driven pick, any density
-                    HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
-                } else if (very_sparse || ctx->record_size < 16u) {
-                    HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
-                } else {
-                    ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
-                    HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
-                }
-            } else if (gt_span_applicable(a) && getenv("PGENHIP_USE_SPAN"))
-                // stream-span kernel: 10 % fewer store instructions than the row-item kernel but more scalar work;
-                // interleaved A/B puts the two within 1-2 % (profiles/r01_kernel_sweeps.md, probe9), so the simpler
-                // row-item kernel stays the default and this one is opt-in
-                HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream));
-            else if (gt_pick_applicable(a) && ctx->sample_count >= 400u && ctx->sample_count < 1400u)
+                    LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
+                else if (very_sparse(ctx) || ctx->record_size < 16u)
+                    LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+                else
+                    LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
+            } else if (gt_pick_applicable(a) && ctx->sample_count >= 400u && ctx->sample_count < 1400u)
                 // short rows (1.6-5.6 KiB of text): batches of rows as one run (gt_pick.hip with the identity for a table) beat both
                 // the flat kernel (N = 1000: 0.50 -> 0.58 of roofline) and the stream kernel's one-row work items (N = 1024: 0.49 -> 0.57)
-                HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
             else if (gt_wide_applicable(a))
-                HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
             else if (gt_flat_applicable(a))
-                HIP_TRY(launch_gt_flat(a, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_gt_flat(a, t, ctx->num_cus, ctx->stream));
             else
-                HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_ROWS:
-            HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
-        case PGENHIP_KERNEL_SCAN: {
-            if (!ctx->subset) return fail(PGENHIP_ERR_BAD_ARG, "scan kernel needs a kept-sample list");
-            if (ctx->record_size < 16u) return fail(PGENHIP_ERR_BAD_ARG, "scan kernel needs N >= 61 (records of >= 16 bytes)");
-            ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
-            HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
+        case PGENHIP_KERNEL_SCAN:
+            if (!ctx->subset) return fail(PGENHIP_ERR_BAD_ARG, "segment kernels need a kept-sample list");
+            if (ctx->record_size < 16u) return fail(PGENHIP_ERR_BAD_ARG, "segment kernels need N >= 61 (records of >= 16 bytes)");
+            LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
-        }
         case PGENHIP_KERNEL_PICK:
             if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "pick kernel needs K >= 4, 61 <= N <= 4096 and out_stride == 4K+1");
-            HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
-            return PGENHIP_OK;
-        case PGENHIP_KERNEL_SPAN:
-            if (!gt_span_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "span kernel needs all samples kept, N >= 2048 and out_stride == 4N+1");
-            HIP_TRY(launch_gt_span(a, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_WIDE:
             if (!gt_wide_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "wide kernel needs all samples kept, N >= 1024 and out_stride == 4N+1");
-            HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        case PGENHIP_KERNEL_RUNS:
+            if (!gt_runs_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "runs kernel needs all samples kept, 8 <= N <= ~2000, dense records and text, no variant gather");
+            LAUNCH_TRY(launch_gt_runs(a, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_FLAT:
             if (!gt_flat_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "flat kernel needs all samples kept and out_stride == 4N+1");
-            HIP_TRY(launch_gt_flat(a, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_gt_flat(a, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         default:
-            return fail(PGENHIP_ERR_BAD_ARG, "requested kernel not applicable to these arguments");
+            return fail(PGENHIP_ERR_BAD_ARG, "unknown kernel id");
     }
 }
 
@@ -365,49 +394,73 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
     a.prefix_off = d_prefix_off;
     a.line_off = d_line_off;
     a.max_line_bytes = max_prefix_bytes + 4ull * ctx->kept_count + 1ull;
+    rc = claim_counters(ctx, a);
+    if (rc) return rc;
+    const Tuning &t = ctx->tune;
+    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
     switch (flags) {
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;
             // all samples kept and rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place
             // behind their prefixes (+ a small prefix copy); otherwise the general kernel assembles whole lines
             if (gt_wide_lines_applicable(a)) {
-                HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
             } else if (gt_pick_applicable(a)) {
-                // kept subset on short records: the pick kernel flushes each parked row behind its prefix
-                HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
-                HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
-            } else if (a.kept_idx != nullptr && ctx->record_size >= 16u &&
-                       !(ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 300ull <= ctx->sample_count)) {
-                // kept subset: the scan-family kernels write each GT segment behind its prefix, the prefix kernel the rest
-                ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
-                HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
-                HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+                // short records (kept subset, or all samples on rows under 4 KiB): the pick kernel flushes each parked row behind its prefix
+                LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+            } else if (a.kept_idx != nullptr && ctx->record_size >= 16u && !very_sparse(ctx)) {
+                // kept subset: the segment kernels write each GT segment behind its prefix, the prefix kernel the rest
+                LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             } else {
-                HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
             }
             return PGENHIP_OK;
         case PGENHIP_KERNEL_ROWS:
-            HIP_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_WIDE:
             if (!gt_wide_lines_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_WIDE needs all samples kept and sample_count >= 1024");
-            HIP_TRY(launch_gt_wide(a, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
-        case PGENHIP_KERNEL_SCAN: {
+        case PGENHIP_KERNEL_SCAN:
             if (!ctx->subset || ctx->record_size < 16u) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_SCAN needs a kept-sample list and N >= 61");
-            ScanArgs sc{ctx->d_keep_words, ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
-            HIP_TRY(launch_gt_scan(a, sc, ctx->num_cus, ctx->stream));
-            HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
-        }
         case PGENHIP_KERNEL_PICK:
             if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_PICK needs K >= 4 and 61 <= N <= 4096");
-            HIP_TRY(launch_gt_pick(a, ctx->num_cus, ctx->stream));
-            HIP_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
+            LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         default:
             return fail(PGENHIP_ERR_BAD_ARG, "pgenhip_emit_lines supports kernel flags AUTO, ROWS, WIDE, SCAN and PICK");
     }
+}
+
+int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value)
+{
+    if (!ctx) return fail(PGENHIP_ERR_BAD_ARG, "ctx is NULL");
+    const Tuning d;  // the defaults
+    Tuning &t = ctx->tune;
+    switch (knob) {
+        case PGENHIP_KNOB_WIDE_BLOCKS_PER_CU: t.wide_blocks_per_cu = value > 0 ? value : d.wide_blocks_per_cu; break;
+        case PGENHIP_KNOB_WIDE_RANGES:
+            if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(PGENHIP_ERR_BAD_ARG, "ranges must be 1, 2, 4 or 8");
+            t.wide_ranges = value ? value : d.wide_ranges;
+            break;
+        case PGENHIP_KNOB_FLAT_BLOCKS_PER_CU: t.flat_blocks_per_cu = value > 0 ? value : d.flat_blocks_per_cu; break;
+        case PGENHIP_KNOB_SCAN_BLOCKS_PER_CU: t.scan_blocks_per_cu = value > 0 ? value : d.scan_blocks_per_cu; break;
+        case PGENHIP_KNOB_SCAN_SUPER:
+            if (value < -1 || value > 1) return fail(PGENHIP_ERR_BAD_ARG, "scan_super must be -1, 0 or 1");
+            t.scan_super = value;
+            break;
+        case PGENHIP_KNOB_PICK_BATCH_BYTES: t.pick_batch_bytes = value > 0 ? value : d.pick_batch_bytes; break;
+        case PGENHIP_KNOB_RUNS_ROWS: t.runs_rows = value > 0 ? value : d.runs_rows; break;
+        default: return fail(PGENHIP_ERR_BAD_ARG, "unknown knob");
+    }
+    return PGENHIP_OK;
 }
 
 int pgenhip_wait(pgenhip_ctx *ctx)

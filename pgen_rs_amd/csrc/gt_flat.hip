@@ -19,8 +19,6 @@
 //
 // (row, col) bookkeeping is incremental: one 64-bit division per block at kernel start, then
 // add-with-carry per grid-stride step — no per-lane division for rows >= 8 KiB.
-#include <stdlib.h>
-
 #include "gt_common.hip.h"
 #include "kernels.h"
 
@@ -226,7 +224,7 @@ bool gt_flat_applicable(const EmitArgs &a)
            (a.n_variants <= 1 || a.out_stride == 4ull * a.kept_count + 1ull);
 }
 
-hipError_t launch_gt_flat(const EmitArgs &a, int num_cus, hipStream_t stream)
+hipError_t launch_gt_flat(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream)
 {
     if (a.n_variants == 0) return hipSuccess;
     FlatParams p;
@@ -234,41 +232,22 @@ hipError_t launch_gt_flat(const EmitArgs &a, int num_cus, hipStream_t stream)
     p.total_bytes = (uint64_t)a.n_variants * p.row_bytes;
     p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 15ull);
     p.n_chunks = (p.head + p.total_bytes + 15ull) / 16ull;
-    // tuning knob (A/B runs only): PGENHIP_FLAT_VARIANT = index into the table below
-    const char *ev = getenv("PGENHIP_FLAT_VARIANT");
-    const int variant = ev ? atoi(ev) : 1;  // U=4 + nontemporal stores (sweep: profiles/r01_kernel_sweeps.md)
-    struct Variant {
-        void (*kern[2][3])(EmitArgs, FlatParams);  // [has_vidx][wrap]
-        uint32_t u;
-    };
-#define PGENHIP_FLAT_VARIANT(U_, NT_, L16_, WC_)                                                        \
-    {                                                                                                   \
-        {{gt_flat_kernel<U_, NT_, L16_, WC_, false, 0>, gt_flat_kernel<U_, NT_, L16_, WC_, false, 1>,    \
-          gt_flat_kernel<U_, NT_, L16_, WC_, false, 2>},                                                \
-         {gt_flat_kernel<U_, NT_, L16_, WC_, true, 0>, gt_flat_kernel<U_, NT_, L16_, WC_, true, 1>,      \
-          gt_flat_kernel<U_, NT_, L16_, WC_, true, 2>}},                                                \
-            U_                                                                                          \
-    }
-    // the round-1 sweep (profiles/r01_kernel_sweeps.md) covered 13 builds; three are kept compiled:
-    static const Variant table[] = {
-        PGENHIP_FLAT_VARIANT(4, false, false, false),  // 0 plain stores
-        PGENHIP_FLAT_VARIANT(4, true, false, false),   // 1 nontemporal stores (default)
-        PGENHIP_FLAT_VARIANT(8, true, true, true),     // 2 U=8, nontemporal, 16-bit window loads, wave-contiguous
-    };
-#undef PGENHIP_FLAT_VARIANT
-    const Variant &vr = table[(variant >= 0 && variant < (int)(sizeof(table) / sizeof(table[0]))) ? variant : 1];
-    const uint32_t tile_chunks = kThreads * vr.u;
+    // U = 4 chunks per lane, nontemporal stores, byte window loads: the best of the 13 builds of the round-1 sweep
+    // (profiles/r01_kernel_sweeps.md; plain stores and U = 8 + 16-bit loads + wave-contiguous spans were the runners-up)
+    constexpr uint32_t kU = 4;
+    static void (*const kern[2][3])(EmitArgs, FlatParams) = {
+        {gt_flat_kernel<kU, true, false, false, false, 0>, gt_flat_kernel<kU, true, false, false, false, 1>, gt_flat_kernel<kU, true, false, false, false, 2>},
+        {gt_flat_kernel<kU, true, false, false, true, 0>, gt_flat_kernel<kU, true, false, false, true, 1>, gt_flat_kernel<kU, true, false, false, true, 2>}};
+    const uint32_t tile_chunks = kThreads * kU;
     const uint32_t tile_bytes = tile_chunks * 16u;
     p.n_tiles = (p.n_chunks + tile_chunks - 1ull) / tile_chunks;
-    const char *eb = getenv("PGENHIP_FLAT_BLOCKS_PER_CU");
-    const int blocks_per_cu = eb ? atoi(eb) : 64;
-    const uint64_t max_grid = (uint64_t)num_cus * (uint64_t)blocks_per_cu;
+    const uint64_t max_grid = (uint64_t)num_cus * (uint64_t)(t.flat_blocks_per_cu > 0 ? t.flat_blocks_per_cu : 64);
     const uint32_t grid = (uint32_t)(p.n_tiles < max_grid ? p.n_tiles : max_grid);
     const uint64_t step = (uint64_t)grid * tile_bytes;
     p.step_rows = step / p.row_bytes;
     p.step_cols = step % p.row_bytes;
     const int wrap = p.row_bytes >= tile_bytes ? 0 : (p.row_bytes >= tile_bytes / 2u ? 1 : 2);
-    hipLaunchKernelGGL(vr.kern[a.variant_idx ? 1 : 0][wrap], dim3(grid), dim3(kThreads), 0, stream, a, p);
+    hipLaunchKernelGGL(kern[a.variant_idx ? 1 : 0][wrap], dim3(grid), dim3(kThreads), 0, stream, a, p);
     return hipGetLastError();
 }
 

@@ -249,7 +249,7 @@ bool gt_pick_applicable(const EmitArgs &a)
            (a.line_off != nullptr || a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull);
 }
 
-hipError_t launch_gt_pick(const EmitArgs &a, int num_cus, hipStream_t stream)
+hipError_t launch_gt_pick(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream)
 {
     if (a.n_variants == 0) return hipSuccess;
     PickParams p;
@@ -258,8 +258,7 @@ hipError_t launch_gt_pick(const EmitArgs &a, int num_cus, hipStream_t stream)
     p.row_bytes = 4u * a.kept_count + 1u;
     // rows per batch: ~32 KiB of text per batch (8 / 16 / 32 / 64 KiB at 50 % kept on the chr22 shape: 1.44 / 1.41 / 1.37 / 1.36 ms),
     // what the stage holds, what the register buffer holds
-    const char *eb = getenv("PGENHIP_PICK_BATCH_BYTES");  // A/B: text per batch (one store drain per batch)
-    const uint32_t batch_bytes = eb && atoi(eb) > 0 ? (uint32_t)atoi(eb) : 32768u;
+    const uint32_t batch_bytes = t.pick_batch_bytes > 0 ? (uint32_t)t.pick_batch_bytes : 32768u;
     uint32_t b = (batch_bytes + p.row_bytes - 1u) / p.row_bytes;
     b = b < 1u ? 1u : b;
     if (b > (uint32_t)kMaxBatchRows) b = (uint32_t)kMaxBatchRows;

@@ -1,25 +1,23 @@
-// gt_scan.hip — kept-subset kernel: input-driven scan + LDS compaction (gfx950 / MI355X).
+// gt_scan.hip — kept-subset kernels for records longer than one tile (gfx950 / MI355X).
 //
 // Replaces /root/reference/src/pfile.rs:165-190 when a sample filter is active
-// (`--include-sam`, kept list from filter_metadata :312-335).  The keep mask is the same for
-// every variant, so it is turned once per context into an N-bit bitmap plus per-segment ranks;
-// the kernel then never touches the kept-index list:
+// (`--include-sam`, kept list from filter_metadata :312-335).  The kept list is the same for
+// every variant, so the context holds it on the device together with the number of kept samples
+// before each SEGMENT of 16 384 samples (4 KiB of every record).  A block owns one segment (or
+// three, gather kernel) and stages ITS SLICE of the kept list once, as u16 offsets in LDS: that
+// slice is the rank -> sample table.  Waves then walk rows: wide 16-B-per-lane loads of the
+// segment's record bytes (next row's loads in flight while this row's text goes out), parked in
+// the wave's LDS stage; the output-driven flush (flush_codes, gt_common.hip.h) gives every lane a
+// 16-byte-ALIGNED chunk of the row's output bytes: five table reads + five staged-byte reads,
+// text, funnel shift by the row's phase, one 16-B store — whole-line coalesced stores however
+// irregular the mask is.  Segment and row edges (partial chunks, '\n') go out as one byte-store
+// instruction per row piece.
 //
-//   * a block owns one SEGMENT of 16 384 samples (4 KiB of every record) and stages that
-//     segment's 256 keep words into LDS once, together with their exclusive popcount prefix
-//     (computed in-kernel: per-lane __popcll + a wave-level shuffle scan);
-//   * each WAVE of the block then walks rows: per 1-KiB tile it issues one coalesced 16-B-per-
-//     lane load of the packed 2-bit words (64 samples per lane), takes its 64-bit keep word and
-//     rank from LDS, and drops the kept codes into its private LDS ring at their final rank
-//     (ctz loop over the set bits — lanes with an empty word skip, a tile whose ballot of
-//     non-empty words is zero is skipped whole);
-//   * output-driven flush: lanes own 16-byte-ALIGNED chunks of the row's output bytes, read five
-//     consecutive codes from the ring, expand to text, funnel-shift by the row's phase and store
-//     16 B — whole-line coalesced stores regardless of how irregular the mask is.  Segment and
-//     row edges (partial chunks, '\n') use masked byte stores.
-//
-// HBM traffic per row: the record once (R bytes, wide loads) + 4K+1 bytes of text; the bitmap
-// (N/8 bytes) is read once per block, not once per row.
+// HBM traffic per row: the record once (R bytes, wide loads) + 4K+1 bytes of text; the kept list
+// once per block, not once per row.
+// (Round 1's first subset kernel — keep bitmap + popcount prefix in LDS, per-lane ctz compaction
+// into a code ring — measured 5-10 % behind the table pick at every density
+// (profiles/r01_kernel_sweeps.md) and was removed in round 2.)
 #include "gt_common.hip.h"
 #include "kernels.h"
 
@@ -30,66 +28,15 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr uint32_t kSegSamples = kScanSegmentSamples;   // 16 384 samples per segment
-constexpr uint32_t kSegWords = kSegSamples / 64;        // 256 keep words
 constexpr uint32_t kTileSamples = 4096;                 // 64 lanes x 64 samples = 1 KiB of record
 constexpr uint32_t kTilesPerSeg = kSegSamples / kTileSamples;
-constexpr uint32_t kRing = 8192;                        // code ring per wave (bytes, power of two)
-constexpr uint32_t kFlushCodes = 2048;                  // pending codes that trigger a mid-segment flush (ring holds 2048 + 4096 + carry)
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-template <uint32_t RING = kRing>
+template <uint32_t RING>
 __device__ __forceinline__ uint32_t ring_code(const uint8_t *ring, uint32_t rel)
 {
     return ring[rel & (RING - 1u)];
-}
-
-// Compaction of one lane's 64 samples of a tile: kept codes go to the ring at their rank
-// (src/pfile.rs:171-175).  `pos` = rank of the lane's first kept sample relative to the segment
-// start, `ring_base` = ring position of the row's rank 0.
-// DENSE: most samples are kept (host decides from K/N): one record byte (4 samples) per step
-// instead of one kept sample per step; a fully kept byte becomes one 4-byte ring write.
-template <bool DENSE>
-__device__ __forceinline__ void compact_lane(uint8_t *ring, uint32_t ring_base, uint64_t lo, uint64_t hi, uint64_t mm, uint32_t pos)
-{
-    pos += ring_base;
-    if (DENSE) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const uint32_t nib = (uint32_t)(mm >> (4 * q)) & 0xFu;
-            if (nib == 0u) continue;
-            const uint32_t x = (uint32_t)((q < 8 ? lo : hi) >> (8 * (q & 7))) & 0xFFu;
-            if (nib == 0xFu) {
-                const uint32_t d = (x & 3u) | ((x & 0xCu) << 6) | ((x & 0x30u) << 12) | ((x & 0xC0u) << 18);
-                const uint32_t idx = pos & (kRing - 1u);
-                if (idx <= kRing - 4u) {
-                    __builtin_memcpy(ring + idx, &d, 4);
-                } else {
-                    ring[idx] = (uint8_t)d;
-                    ring[(idx + 1u) & (kRing - 1u)] = (uint8_t)(d >> 8);
-                    ring[(idx + 2u) & (kRing - 1u)] = (uint8_t)(d >> 16);
-                    ring[(idx + 3u) & (kRing - 1u)] = (uint8_t)(d >> 24);
-                }
-                pos += 4u;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (nib & (1u << e)) {
-                        ring[pos & (kRing - 1u)] = (uint8_t)((x >> (2 * e)) & 3u);
-                        pos++;
-                    }
-                }
-            }
-        }
-    } else {
-        while (mm != 0ull) {
-            const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
-            mm &= mm - 1ull;
-            const uint64_t half = bit < 32u ? lo : hi;
-            ring[pos & (kRing - 1u)] = (uint8_t)((half >> ((bit & 31u) * 2u)) & 3ull);
-            pos++;
-        }
-    }
 }
 
 // A lane's 16 record bytes as two 64-bit halves; a window that was pulled back by `tail_shift`
@@ -113,161 +60,12 @@ __device__ __forceinline__ void window_halves(const v4u &w, uint32_t tail_shift,
 // chunk (segment / row edges, shared with the neighbouring segment's block) go out as ONE
 // byte-store instruction: lanes 0-15 take the head bytes, lanes 16-31 the tail bytes.
 // All 64-bit arithmetic is wave-uniform (scalar unit); a lane only adds a 32-bit offset.
-template <uint32_t RING = kRing>
+template <uint32_t RING>
 __device__ __forceinline__ void flush_range(const uint8_t *ring, uint32_t ring_base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
                                             uint32_t seg_k0, uint32_t K, uint32_t lane)
 {
     flush_codes([ring](uint32_t x) { return ring_code<RING>(ring, x); }, ring_base, row_out, emitted, hi_emit, seg_k0, K, lane);
 }
-
-// Stage a segment's keep words and their exclusive popcount prefix (once per block; needs all of
-// the block's first 256 threads and two barriers).
-__device__ __forceinline__ void stage_segment(const ScanArgs &sc, uint32_t seg, uint64_t *s_mask, uint32_t *s_pre, uint32_t tid)
-{
-    const uint32_t lane = tid & 63u;
-    if (tid < kSegWords) s_mask[tid] = sc.keep_words[(uint64_t)seg * kSegWords + tid];
-    __syncthreads();
-    if (tid < 64u) {
-        // lane handles words 4*lane .. 4*lane+3; wave scan over the lane totals
-        uint32_t c0 = __popcll(s_mask[4u * lane]), c1 = __popcll(s_mask[4u * lane + 1u]);
-        uint32_t c2 = __popcll(s_mask[4u * lane + 2u]), c3 = __popcll(s_mask[4u * lane + 3u]);
-        uint32_t tot = c0 + c1 + c2 + c3;
-        uint32_t incl = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t up = __shfl_up(incl, d, 64);
-            if ((int)lane >= d) incl += up;
-        }
-        uint32_t excl = incl - tot;
-        s_pre[4u * lane] = excl;
-        s_pre[4u * lane + 1u] = excl + c0;
-        s_pre[4u * lane + 2u] = excl + c0 + c1;
-        s_pre[4u * lane + 3u] = excl + c0 + c1 + c2;
-        if (lane == 63u) s_pre[kSegWords] = incl;
-    }
-    __syncthreads();
-}
-
-// A separate DENSE instantiation keeps the sparse build's registers low.
-template <bool HAS_VIDX, bool DENSE>
-__global__ __launch_bounds__(kThreads) void gt_scan_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups)
-{
-    __shared__ uint64_t s_mask[kSegWords];
-    __shared__ uint32_t s_pre[kSegWords + 1];
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kWaves][kRing];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t seg = blockIdx.x % n_seg;
-    const uint32_t row_group = blockIdx.x / n_seg;
-
-    stage_segment(sc, seg, s_mask, s_pre, tid);
-
-    uint8_t *const ring = s_ring[wave];
-    const uint32_t K = a.kept_count;
-    const uint32_t seg_k0 = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg]);  // kept samples before this segment
-    const uint32_t seg_cnt = __builtin_amdgcn_readfirstlane(s_pre[kSegWords]);   // kept samples inside it
-    const bool last_seg = seg + 1u == n_seg;
-    const uint32_t seg_byte0 = seg * (kSegSamples / 4u);      // first record byte of the segment
-    const uint32_t R = a.record_size;
-    if (seg_cnt == 0u && !last_seg) return;                   // nothing of this segment is kept
-
-    // the keep word and rank of this lane's 64 samples in each tile do not depend on the row:
-    // take them out of LDS once
-    uint64_t m[kTilesPerSeg];
-    uint32_t pre[kTilesPerSeg], tile_end[kTilesPerSeg];
-    uint32_t live_tiles = 0u;  // tiles with at least one kept sample (wave-uniform bit set)
-#pragma unroll
-    for (uint32_t t = 0; t < kTilesPerSeg; t++) {
-        m[t] = s_mask[t * 64u + lane];
-        pre[t] = s_pre[t * 64u + lane];
-        tile_end[t] = s_pre[t * 64u + 64u];
-        if (__ballot(m[t] != 0ull) != 0ull) live_tiles |= 1u << t;
-    }
-
-    const uint64_t row_step = (uint64_t)row_groups * kWaves;
-    uint64_t j = (uint64_t)row_group * kWaves + wave;
-    if (j >= a.n_variants) return;
-
-    // ---- coalesced wide loads of the packed 2-bit words: 16 B (64 samples) per lane and tile,
-    // all tiles of the segment in flight at once, and the NEXT row's requested before this row is
-    // processed (register double buffering)
-    v4u cur[kTilesPerSeg], nxt[kTilesPerSeg];
-    // Branch-free: every lane always loads 16 bytes from inside the record (R >= 16 is a launch
-    // precondition).  A window that would run past the record end (last lane of the last tile) is
-    // pulled back to R-16 and the bytes are shifted into place at use time (`tail_shift`), so no
-    // conditional byte loop — and with it no early s_waitcnt — sits between the loads.
-    uint32_t tail_shift[kTilesPerSeg];
-#pragma unroll
-    for (uint32_t t = 0; t < kTilesPerSeg; t++) {
-        const uint32_t b = seg_byte0 + t * 1024u + lane * 16u;
-        tail_shift[t] = b + 16u <= R ? 0u : min(b - (R - 16u), 16u);
-    }
-    auto load_row = [&](uint64_t row, v4u(&dst)[kTilesPerSeg]) {
-        const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
-        const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
-#pragma unroll
-        for (uint32_t t = 0; t < kTilesPerSeg; t++) {
-            const uint32_t b = min(seg_byte0 + t * 1024u + lane * 16u, R - 16u);
-            __builtin_memcpy(&dst[t], rec + b, 16);
-        }
-    };
-    load_row(j, cur);
-
-    for (;;) {
-        const uint64_t j_next = j + row_step;
-        const bool more = j_next < a.n_variants;
-        // gfx9 has ONE in-order vmcnt: make this row's words land before the next row's are
-        // requested (they were issued a whole row ago, so this wait is short), otherwise the first
-        // use of `cur` below would also wait for the loads issued here
-#pragma unroll
-        for (uint32_t t = 0; t < kTilesPerSeg; t++) asm volatile("" ::"v"(cur[t].x), "v"(cur[t].y), "v"(cur[t].z), "v"(cur[t].w));
-        if (more) load_row(j_next, nxt);
-
-        uint8_t *const row_out = row_text(a, j);               // byte 0 of this row's GT segment
-        const uint64_t row_addr = (uint64_t)(uintptr_t)row_out;
-        uint64_t emitted = 4ull * seg_k0;                      // next row byte this wave must write
-        uint32_t produced = 0u;                                // codes in the ring (rank relative to seg_k0)
-
-#pragma unroll
-        for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
-            if (live_tiles & (1u << tile)) {
-                // ---- compaction: kept codes go to the ring at their rank (src/pfile.rs:171-175)
-                uint64_t lo, hi;
-                window_halves(cur[tile], tail_shift[tile], lo, hi);
-                compact_lane<DENSE>(ring, 0u, lo, hi, m[tile], pre[tile]);
-            }
-            produced = tile_end[tile];
-            const bool final = tile + 1u == kTilesPerSeg || produced == seg_cnt;
-            // flush when the segment is done, or when enough text is pending to fill whole stores
-            const uint64_t avail = 4ull * ((uint64_t)seg_k0 + produced);
-            if (!final && avail - emitted < 4ull * kFlushCodes) continue;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-            // ---- flush: row bytes [emitted, hi_emit) are now determined
-            uint64_t hi_emit;
-            if (final)
-                hi_emit = avail + (last_seg ? 1ull : 0ull);             // '\n' closes the row (:190)
-            else
-                hi_emit = ((row_addr + avail) & ~15ull) - row_addr;     // keep the partial chunk for later
-            if ((int64_t)hi_emit > (int64_t)emitted) {
-                flush_range(ring, 0u, row_out, emitted, hi_emit, seg_k0, K, lane);
-                emitted = hi_emit;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (final) break;
-        }
-        if (!more) break;
-#pragma unroll
-        for (uint32_t t = 0; t < kTilesPerSeg; t++) cur[t] = nxt[t];
-        j = j_next;
-    }
-}
-
 
 // ---- constants of the sparse-keep gather kernel below -------------------------------------------
 constexpr uint32_t kGatherRing = 4096;                               // codes per wave
@@ -440,15 +238,15 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
 
 // ---------------------------------------------------------------------------------------------
 // gt_scan_pick_kernel — the default kernel for kept subsets on records longer than one tile, any
-// density.  The per-lane ctz compaction of
-// gt_scan_kernel costs 150-300 VALU instructions per store step there; this kernel has no
+// density.  The per-lane ctz compaction of round 1's first subset kernel
+// cost 150-300 VALU instructions per store step there; this kernel has no
 // compaction at all (the idea of gt_pick.hip, per segment): the block's slice of the context's
 // kept list, as u16 offsets into the segment, IS the rank -> sample table in LDS; a wave parks a
 // row's 4 KiB of record bytes in its LDS stage and the output-driven flush (flush_codes) picks
 // every genotype straight from there: one table read + one staged-byte read per genotype.
 // A row piece is >= 4 KiB of text here, so the one store drain per row piece is amortised.  Against the DENSE
-// instantiation of gt_scan_kernel (> 75 % kept: whole record bytes per step) it is 4-6 % faster as well
-// (0.545 -> 0.566 of roofline at all-but-7 kept), so gt_scan_kernel is only the A/B partner now.
+// instantiation of that kernel (> 75 % kept: whole record bytes per step) it was 4-6 % faster as well
+// (0.545 -> 0.566 of roofline at all-but-7 kept).
 constexpr uint32_t kPickMaxSegCodes = kSegSamples;             // up to a fully kept segment: 32 KiB of LDS for the table
 
 template <bool HAS_VIDX>
@@ -555,49 +353,39 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
 // Every block walks the same number of rows, so the launch must be exactly ONE resident round: a grid
 // that exceeds residency by a few blocks runs those in a second round that takes as long as the first.
 template <typename Kern>
-static uint32_t resident_blocks(Kern kern, int threads, int num_cus)
+static uint32_t resident_blocks(Kern kern, int threads, int num_cus, const Tuning &t)
 {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    const char *eb = getenv("PGENHIP_SCAN_BLOCKS_PER_CU");
-    if (eb && atoi(eb) > 0) per_cu = atoi(eb);
+    if (t.scan_blocks_per_cu > 0) per_cu = t.scan_blocks_per_cu;
     return (uint32_t)per_cu * (uint32_t)num_cus;
 }
 
-hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hipStream_t stream)
+hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t, int num_cus, hipStream_t stream)
 {
     if (a.n_variants == 0) return hipSuccess;
+    if (a.kept_idx == nullptr) return hipErrorInvalidValue;
     const uint32_t n_seg = (a.sample_count + kSegSamples - 1u) / kSegSamples;
     const uint32_t n_seg_eff = n_seg ? n_seg : 1u;
     const uint64_t groups_needed = ((uint64_t)a.n_variants + kWaves - 1ull) / kWaves;
-    // Three kernels (interleaved A/B in profiles/r01_kernel_sweeps.md):
+    // Two kernels (interleaved A/B in profiles/r01_kernel_sweeps.md):
     //  * the segment pick kernel — default for every density;
     //  * the three-segment gather kernel in the one band where it measured ahead (0.8-2 % kept on records of three
-    //    segments or more: config 5; 0.3 % / 0.6 % / 1 % / 2 % kept: pick 1.53 / 1.68 / 1.76 / 2.23 ms, gather 1.62 / 1.75 / 1.72 / 2.14); PGENHIP_SCAN_SUPER=0/1 overrides the band (1 still needs the ring precondition);
-    //  * the per-lane ctz kernel (DENSE instantiation above 75 % kept) as A/B partner: PGENHIP_SCAN_PICK=0.
-    const char *eu = getenv("PGENHIP_SCAN_SUPER");
-    const char *ep = getenv("PGENHIP_SCAN_PICK");
+    //    segments or more: config 5; 0.3 % / 0.6 % / 1 % / 2 % kept: pick 1.53 / 1.68 / 1.76 / 2.23 ms, gather 1.62 / 1.75 / 1.72 / 2.14);
+    //    Tuning::scan_super = 0 / 1 overrides the band (1 still needs the ring precondition).
     const bool band = n_seg_eff >= kSubSegs && (uint64_t)a.kept_count * 125ull >= (uint64_t)a.sample_count;  // >= 0.8 % kept
-    const bool super_kernel = a.kept_idx != nullptr && sc.max_super_count <= kGatherMaxSegCodes && (eu ? atoi(eu) != 0 : band);
+    const bool super_kernel = sc.max_super_count <= kGatherMaxSegCodes && (t.scan_super >= 0 ? t.scan_super != 0 : band);
     if (super_kernel) {
         void (*k3)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t) = a.variant_idx ? gt_scan_gather3_kernel<true> : gt_scan_gather3_kernel<false>;
         const uint32_t n_super = (n_seg_eff + kSubSegs - 1u) / kSubSegs;
-        uint64_t groups = (uint64_t)resident_blocks(k3, kThreads, num_cus) / n_super;
+        uint64_t groups = (uint64_t)resident_blocks(k3, kThreads, num_cus, t) / n_super;
         if (groups < 1ull) groups = 1ull;
         if (groups > groups_needed) groups = groups_needed;
         hipLaunchKernelGGL(k3, dim3((uint32_t)(groups * n_super)), dim3(kThreads), 0, stream, a, sc, n_seg_eff, n_super, (uint32_t)groups);
         return hipGetLastError();
     }
-    const bool pick_kernel = a.kept_idx != nullptr && sc.max_seg_count <= kPickMaxSegCodes && (ep ? atoi(ep) != 0 : true);
-    const bool dense = (uint64_t)a.kept_count * 4ull > (uint64_t)a.sample_count * 3ull;  // > 75 % kept
-    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t);
-    if (pick_kernel)
-        kern = a.variant_idx ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
-    else if (a.variant_idx)
-        kern = dense ? gt_scan_kernel<true, true> : gt_scan_kernel<true, false>;
-    else
-        kern = dense ? gt_scan_kernel<false, true> : gt_scan_kernel<false, false>;
-    uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus) / n_seg_eff;  // floor: never a partial second round
+    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t) = a.variant_idx ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
+    uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus, t) / n_seg_eff;  // floor: never a partial second round
     if (groups < 1ull) groups = 1ull;  // more segments than resident blocks (N > ~16 M samples): rounds are unavoidable
     if (groups > groups_needed) groups = groups_needed;
     const uint32_t grid = (uint32_t)(groups * n_seg_eff);

@@ -19,9 +19,6 @@
 // (register double-buffering), so loads stay in flight behind the store stream.
 // The chunk that holds a row's '\n' also holds the head of row j+1: its first bytes come from a
 // direct byte load (one lane per row).  Stream head/tail chunks use masked byte stores.
-#include <stdio.h>
-#include <stdlib.h>
-
 #include "gt_common.hip.h"
 #include "kernels.h"
 
@@ -29,8 +26,6 @@ namespace pgenhip {
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
 constexpr uint32_t kSpanChunks = 1024;  // chunks per work item: 16 stores x 64 lanes
 constexpr uint32_t kSlabBytes = 1088;   // 66 lanes x 16 B staged at most, rounded to 64
 constexpr uint32_t kSlabExtra = 16;     // stream kernels: +0 u8 = first record byte of row j+1 (for the chunk holding row j's '\n')
@@ -48,7 +43,8 @@ struct WideParams {
     uint32_t spans_per_row;
     uint32_t head;           // out address & 127: the chunk grid is anchored at a 128-B line boundary
     uint32_t n_ranges;       // work-queue kernel: contiguous item ranges with a head word each (1, 2, 4 or 8)
-    uint64_t *dbg;           // diagnostic builds only (PGENHIP_DEBUG_TIMES=1): per-wave {start, end, items} stamps, else nullptr
+    uint32_t run_rows;       // RUNS mode: rows per work item (B)
+    uint32_t magic;          // RUNS mode: floor(2^32 / S) + 1: o / S = umulhi(o, magic), fixed up by one compare (o < 2^14)
 };
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -128,14 +124,6 @@ __device__ __forceinline__ Item make_item_at(const EmitArgs &a, const WideParams
     it.n_load = it.cnt ? (mis + (b_last - b_first)) / 16u + 1u : 0u;
     it.delta = (int32_t)mis - (int32_t)b_first;
     return it;
-}
-
-template <bool HAS_VIDX>
-__device__ __forceinline__ Item make_item(const EmitArgs &a, const WideParams &p, uint64_t t)
-{
-    const uint64_t j = p.spans_per_row == 1u ? t : t / p.spans_per_row;
-    const uint32_t k = p.spans_per_row == 1u ? 0u : (uint32_t)(t - j * p.spans_per_row);
-    return make_item_at<HAS_VIDX>(a, p, j, k);
 }
 
 
@@ -348,157 +336,147 @@ __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p
     }
 }
 
-template <bool HAS_VIDX, bool NT>
-__global__ __launch_bounds__(kThreads) void gt_wide_kernel(EmitArgs a, WideParams p)
+
+// ---------------------------------------------------------------------------------------------
+// RUNS mode — SHORT rows (N <= ~2000: the reference's own 300-sample datasets, data/basic2 and
+// data/random1).  A row of 1 201 bytes is a poor work item: 75 chunks, a quarter of a record tile,
+// a '\n' merge in every store step.  With dense records (record_stride == R, no variant gather) B
+// consecutive rows are ONE contiguous run of B*R record bytes and ONE contiguous run of B*S text
+// bytes, so the item becomes (rows t*B .. t*B+B-1): the loader fetches the whole run — plus the
+// first byte of the row behind it — with a single 16-B-per-lane load (B*R <= 1 040), and a storer
+// walks the run's 16-byte-ALIGNED chunks exactly like a long row's: chunk at run offset o lies in
+// row o / S (one multiply-high by a host-computed reciprocal) at row byte o % S; its window is two
+// bytes of the slab.  The chunks that hold a '\n' (one per row) are NOT built in the store steps,
+// where one such lane would drag the whole wave through the merge path every step; they are left
+// out of the step's store (the lane is masked) and written afterwards in one pass with lane r on
+// row r's '\n' chunk: tail of row r, '\n', head of row r+1, all from the slab.  The line such a
+// chunk lives in is completed within microseconds by the same wave, so L2 merges the two writes.
+__device__ __forceinline__ Item make_run_item(const EmitArgs &a, const WideParams &p, uint64_t t)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t slabs[kWaves][kSlabBytes];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR item math
-    uint8_t *const slab = slabs[wave];
-    const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
+    Item it;
+    const uint32_t S = (uint32_t)p.row_bytes;
+    const uint32_t R = a.record_size;
+    const uint64_t row0 = t * (uint64_t)p.run_rows;
+    const uint32_t nrows = (uint32_t)min((uint64_t)p.run_rows, (uint64_t)a.n_variants - row0);
+    const uint64_t run_start = row0 * (uint64_t)S;
+    const uint32_t run_len = nrows * S;
+    // the run owns the chunks whose first byte lies inside it; run 0 also the chunk that holds stream byte 0
+    const uint64_t g_first = t == 0ull ? (run_start + p.head) >> 4 : (run_start + p.head + 15ull) >> 4;
+    const uint64_t g_end = (run_start + run_len + p.head + 15ull) >> 4;
+    it.row = row0;
+    it.g0 = g_first;
+    it.cnt = (uint32_t)(g_end - g_first);
+    it.lead = (uint32_t)g_first & 63u;  // one span per item: store step u covers chunks (g_first - lead) + 64u .. +63
+    it.c_first = (int64_t)(int32_t)((uint32_t)g_first * 16u - p.head - (uint32_t)run_start);  // run-relative offset of chunk g_first: -15 .. 15
+    it.row_tail = false;
+    it.rec = a.records + row0 * (uint64_t)R;  // dense records: the run's record bytes are contiguous
+    // record bytes of the run + the first byte of the row behind it (head of the chunk holding the run's last '\n')
+    const uint32_t n_bytes = nrows * R + (row0 + nrows < (uint64_t)a.n_variants ? 1u : 0u);
+    const uint32_t mis = (uint32_t)((uint64_t)(uintptr_t)it.rec & 15ull);
+    it.base = it.rec - mis;
+    it.n_load = (mis + n_bytes + 15u) / 16u;  // <= 66 (host: B * R <= 1 040)
+    it.delta = (int32_t)mis;
+    return it;
+}
 
-    uint64_t t = (uint64_t)blockIdx.x * kWaves + wave;
-    if (t >= p.n_items) return;
-    const uint64_t dbg_slot = ((uint64_t)blockIdx.x * kWaves + wave) * 3ull;
-    uint64_t dbg_items = 0;
-    if (p.dbg && lane == 0u) p.dbg[dbg_slot] = __builtin_amdgcn_s_memrealtime();
+// 16 text bytes of the run starting at row byte `pos` of the row whose record starts at slab offset `rec_off`
+__device__ __forceinline__ u32x4 run_text16(const uint8_t *slab, uint32_t rec_off, uint32_t pos)
+{
+    uint16_t h;
+    __builtin_memcpy(&h, slab + rec_off + (pos >> 4), 2);
+    return gt_text16_from_window((uint32_t)h, (int64_t)pos);
+}
 
-    Item cur = make_item<HAS_VIDX>(a, p, t);
-    v4u in0 = {0u, 0u, 0u, 0u}, in1 = {0u, 0u, 0u, 0u};
-    if (lane < cur.n_load) in0 = *reinterpret_cast<const v4u *>(cur.base + lane * 16u);
-    if (lane + 64u < cur.n_load) in1 = *reinterpret_cast<const v4u *>(cur.base + (lane + 64u) * 16u);
-
-    for (;;) {
-        // ---- park this item's record bytes in the wave's slab
-        *reinterpret_cast<v4u *>(slab + lane * 16u) = in0;
-        if (lane < 4u) *reinterpret_cast<v4u *>(slab + (lane + 64u) * 16u) = in1;
-
-        // ---- request the next item's bytes before this item's stores go out
-        const uint64_t t_next = t + n_waves;
-        const bool more = t_next < p.n_items;
-        Item nxt = cur;
-        if (more) {
-            nxt = make_item<HAS_VIDX>(a, p, t_next);
-            if (lane < nxt.n_load) in0 = *reinterpret_cast<const v4u *>(nxt.base + lane * 16u);
-            if (lane + 64u < nxt.n_load) in1 = *reinterpret_cast<const v4u *>(nxt.base + (lane + 64u) * 16u);
+template <bool NT>
+__device__ __forceinline__ void emit_run(const EmitArgs &a, const WideParams &p, const Item &it, const uint8_t *slab, uint32_t lane)
+{
+    const uint32_t S = (uint32_t)p.row_bytes;
+    const uint32_t R = a.record_size;
+    uint8_t *const chunk0 = a.out - p.head;
+    const int32_t c_first = (int32_t)it.c_first;
+    const uint32_t delta = (uint32_t)it.delta;
+    const uint32_t nrows = (uint32_t)min((uint64_t)p.run_rows, (uint64_t)a.n_variants - it.row);
+    uint8_t *const span_ptr = chunk0 + (it.g0 - it.lead) * 16ull + lane * 16u;  // lane's chunk in step 0
+    const uint32_t end = it.lead + it.cnt;
+    // ---- store steps: every chunk that lies wholly inside one row's GT text
+    for (uint32_t u = 0; u * 64u < end; u++) {
+        const uint32_t i = u * 64u + lane - it.lead;                  // chunk of this item (wraps to huge before `lead`)
+        const int32_t o_s = c_first + 16 * (int32_t)i;
+        const uint32_t o = (uint32_t)max(o_s, 0);
+        uint32_t r = __umulhi(o, p.magic);
+        uint32_t rs = __umul24(r, S);
+        if (rs > o) {
+            r--;
+            rs -= S;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        emit_item<HAS_VIDX, NT, false>(a, p, cur, slab, lane);
-        dbg_items++;
-        if (!more) break;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        cur = nxt;
-        t = t_next;
+        const uint32_t pos = o - rs;
+        const bool plain = i < it.cnt && o_s >= 0 && pos + 17u <= S;  // bytes pos .. pos+15 are GT text of row r
+        if (plain) store_chunk<NT>(span_ptr + u * 1024u, run_text16(slab, delta + __umul24(min(r, nrows - 1u), R), pos));
     }
-    if (p.dbg && lane == 0u) {
-        p.dbg[dbg_slot + 1] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[dbg_slot + 2] = dbg_items;
+    // ---- the '\n' chunks, one per row: lane rr builds row rr's
+    for (uint32_t rr = lane; rr < nrows; rr += 64u) {
+        const uint32_t e = rr * S + S - 1u;                            // run offset of the row's '\n'
+        const uint32_t i = (uint32_t)((int32_t)e - c_first) >> 4;      // its chunk (e >= 32 > c_first)
+        const uint32_t nl = (uint32_t)((int32_t)e - c_first) & 15u;    // its byte inside that chunk
+        const uint32_t pos = S - 1u - nl;                              // row byte of the chunk's first byte (>= 17)
+        const uint32_t rec_off = delta + rr * R;
+        const u32x4 x = run_text16(slab, rec_off, pos);
+        const bool has_next = it.row + rr + 1ull < (uint64_t)a.n_variants;
+        u32x4 y = {0u, 0u, 0u, 0u};
+        if (nl < 15u && has_next) y = gt_text16_from_window((uint32_t)slab[rec_off + R] << 8, -(int64_t)nl - 1);  // record byte -1 (none) and byte 0 of row rr+1
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+        const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
+        uint32_t os[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int32_t nb = (int32_t)nl - 4 * m;  // bytes of dword m taken from row rr
+            const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+            uint32_t d = (xs[m] & mask) | (ys[m] & ~mask);
+            if (nb >= 0 && nb < 4) d = (d & ~(0xFFu << (8 * nb))) | (0x0Au << (8 * nb));
+            os[m] = d;
+        }
+        uint8_t *const dst = chunk0 + (it.g0 + i) * 16ull;
+        if (has_next || nl == 15u) {
+            store_chunk<NT>(dst, u32x4{os[0], os[1], os[2], os[3]});
+        } else {
+            // last row of the whole stream: the chunk ends at the '\n', bytes behind it are not ours
+#pragma unroll
+            for (int b = 0; b < 16; b++)
+                if ((uint32_t)b <= nl) dst[b] = (uint8_t)(os[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+    // ---- run 0 with an unaligned output pointer: the bytes of chunk 0 that belong to the stream (all in row 0's text: S >= 33)
+    if (c_first < 0 && it.cnt != 0u && lane < 16u && (int32_t)lane + c_first >= 0) {
+        const uint32_t ob = (uint32_t)((int32_t)lane + c_first);
+        const uint32_t code = ((uint32_t)slab[delta + (ob >> 4)] >> (((ob >> 2) & 3u) * 2u)) & 3u;
+        chunk0[it.g0 * 16ull + lane] = (uint8_t)gt_text_byte(code, ob & 3u);
     }
 }
 
-
 // ---------------------------------------------------------------------------------------------
-// gt_stream_kernel — the same items, but with ROLES: wave 0 of a block only loads (global ->
-// registers -> LDS slabs), waves 1..NS only store (LDS -> text -> global).  gfx9 counts loads and
-// stores in one in-order vmcnt, so a wave that consumes a load must also wait for all of its
-// older stores; a storer wave here never waits on vmcnt, and its 1-KiB stores stream back to
-// back like a fill kernel's, while the loader keeps NS wide loads in flight one ring slot ahead.
+// gt_stream_dyn_kernel — ROLES: wave 0 of a block only loads (global -> registers -> LDS slabs),
+// waves 1..NS only store (LDS -> text -> global).  gfx9 counts loads and stores in one in-order
+// vmcnt, so a wave that consumes a load must also wait for all of its older stores; a storer wave
+// here never waits on vmcnt, and its 1-KiB stores stream back to back like a fill kernel's, while
+// the loader keeps NS wide loads in flight one ring slot ahead.
 // Hand-off through LDS: per storer a ring of kRingSlots slabs, `full` / `done` sequence words
 // (LDS operations of one wave execute in order, and both waves live on one CU, so a flag written
 // after the slab's ds_writes is seen after them; compiler ordering is pinned with asm barriers).
+// (Round 1 also carried a symmetric-wave kernel and a static-partition role kernel as A/B partners:
+// 0.54 and 0.61 of roofline against this kernel's 0.66-0.73 on the chr22 block, profiles/r01_*; removed.)
 constexpr int kRingSlots = 3;
 constexpr int kDescSlots = kRingSlots + 1;  // slot s % 4 was last read in step s-4, whose `done` the loader saw in step s-1
 
-
-template <int NS, bool HAS_VIDX, bool NT>
-__global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_kernel(EmitArgs a, WideParams p)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][kRingSlots][kSlabBytes + kSlabExtra];
-    __shared__ __attribute__((aligned(16))) uint8_t s_desc[NS][kDescSlots][kDescBytes];
-    __shared__ uint32_t s_full[NS][kRingSlots];
-    __shared__ uint32_t s_done[NS][kRingSlots];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x < NS * kRingSlots) {
-        (&s_full[0][0])[threadIdx.x] = 0u;
-        (&s_done[0][0])[threadIdx.x] = 0u;
-    }
-    __syncthreads();
-
-    const uint64_t items_per_step = (uint64_t)gridDim.x * NS;
-    const uint64_t n_steps = (p.n_items + items_per_step - 1ull) / items_per_step;
-
-    if (wave == 0u) {
-        // ------------------------------ loader wave ------------------------------
-        for (uint64_t step = 0; step < n_steps; step++) {
-            const uint32_t slot = (uint32_t)(step % kRingSlots);
-            v4u in0[NS], in1[NS];
-            uint32_t nb[NS];
-            // issue every storer's loads for this step, then park them
-#pragma unroll
-            for (int w = 0; w < NS; w++) {
-                const uint64_t t = step * items_per_step + (uint64_t)blockIdx.x * NS + w;
-                nb[w] = 0u;
-                in0[w] = v4u{0u, 0u, 0u, 0u};
-                in1[w] = v4u{0u, 0u, 0u, 0u};
-                if (t < p.n_items) {
-                    const Item it = make_item<HAS_VIDX>(a, p, t);
-                    if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], it, t);
-                    if (lane < it.n_load) in0[w] = *reinterpret_cast<const v4u *>(it.base + lane * 16u);
-                    if (lane + 64u < it.n_load) in1[w] = *reinterpret_cast<const v4u *>(it.base + (lane + 64u) * 16u);
-                    // the chunk holding this row's '\n' needs the first record byte of row j+1
-                    const bool row_tail = it.cnt != 0u && it.c_first + 16ll * (int64_t)it.cnt >= (int64_t)p.row_bytes;
-                    if (row_tail && it.row + 1ull < a.n_variants && lane == 0u)
-                        nb[w] = (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
-                }
-            }
-#pragma unroll
-            for (int w = 0; w < NS; w++) {
-                const uint64_t t = step * items_per_step + (uint64_t)blockIdx.x * NS + w;
-                if (t >= p.n_items) continue;
-                // the slot's previous tenant (step - kRingSlots) must have been consumed
-                if (step >= (uint64_t)kRingSlots) {
-                    const uint32_t want = (uint32_t)(step - kRingSlots) + 1u;
-                    while (lds_flag_read(lds_offset(&s_done[w][slot])) != want) __builtin_amdgcn_s_sleep(1);
-                }
-                uint8_t *slab = slabs[w][slot];
-                *reinterpret_cast<v4u *>(slab + lane * 16u) = in0[w];
-                if (lane < 4u) *reinterpret_cast<v4u *>(slab + (lane + 64u) * 16u) = in1[w];
-                if (lane == 0u) slab[kSlabBytes] = (uint8_t)nb[w];
-                if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), (uint32_t)step + 1u);
-            }
-        }
-    } else {
-        // ------------------------------ storer waves -----------------------------
-        const uint32_t w = wave - 1u;
-        for (uint64_t step = 0; step < n_steps; step++) {
-            const uint64_t t = step * items_per_step + (uint64_t)blockIdx.x * NS + w;
-            if (t >= p.n_items) break;
-            const uint32_t slot = (uint32_t)(step % kRingSlots);
-            while (lds_flag_read(lds_offset(&s_full[w][slot])) != (uint32_t)step + 1u) __builtin_amdgcn_s_sleep(1);
-            const Item it = desc_get_item(s_desc[w][step % kDescSlots]);
-            emit_item<HAS_VIDX, NT, true>(a, p, it, slabs[w][slot], lane);
-            // every ds_read of the slab has returned (its data fed the stores above): release the slot
-            if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), (uint32_t)step + 1u);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// gt_stream_dyn_kernel — gt_stream_kernel with a WORK QUEUE instead of a static item partition.
-// Only ~3 of these 512-thread blocks fit on a CU, so a static grid-stride split of a big grid runs
-// in rounds and the last, partly filled round is a tail of several hundred microseconds on a
-// 2.4 ms launch (measured with per-wave s_memrealtime stamps).  Here the items are cut into
+// WORK QUEUE instead of a static item partition: only 4 of these 512-thread blocks fit on a CU, so
+// a static grid-stride split of a big grid runs in rounds and the last, partly filled round is a
+// tail of several hundred microseconds on a 2.4 ms launch (measured with per-wave s_memrealtime
+// stamps).  Here the items are cut into
 // contiguous ranges (two by default — one per XCD measured 1 % slower; picked by blockIdx & (n - 1)); the
 // loader wave claims NS consecutive items per step with one returning atomicAdd on its range's
 // head word (heads live 128 B apart; ~10 claims/us per word, far below the ~88/us a word takes)
 // and steals from the next range when its own is drained.  Every block therefore runs until the
 // whole launch is out of work and all of them finish within one step of each other.
-template <int NS, bool HAS_VIDX, bool NT, bool LINES = false, int BURST = 2>
+template <int NS, bool HAS_VIDX, bool NT, bool LINES = false, int BURST = 2, bool RUNS = false>
 __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a, WideParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][kRingSlots][kSlabBytes + kSlabExtra];
@@ -557,7 +535,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             // one division per step: the step's items are consecutive, so (row, span) just counts on
             uint64_t j_it = 0ull;
             uint32_t k_it = 0u;
-            if (t0 != kNoItem) {
+            if (!RUNS && t0 != kNoItem) {
                 j_it = p.spans_per_row == 1u ? t0 : t0 / p.spans_per_row;
                 k_it = p.spans_per_row == 1u ? 0u : (uint32_t)(t0 - j_it * p.spans_per_row);
             }
@@ -593,8 +571,8 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)rs_lo, (int)r);
                         row_start = ((uint64_t)hi << 32) | (uint64_t)lo;
                     }
-                    const Item it = make_item_at<HAS_VIDX, LINES>(a, p, j_it, k_it, row_start);
-                    if (++k_it == p.spans_per_row) {
+                    const Item it = RUNS ? make_run_item(a, p, t0 + (uint64_t)w) : make_item_at<HAS_VIDX, LINES>(a, p, j_it, k_it, row_start);
+                    if (!RUNS && ++k_it == p.spans_per_row) {
                         k_it = 0u;
                         j_it++;
                     }
@@ -605,7 +583,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                         ext_on = 64u + (lane & 1u) < it.n_load;
                     }
                     // rows < n_variants <= 2^32 - 1, so row + 1 fits 32 bits
-                    if (!LINES && it.row_tail && (uint32_t)it.row + 1u < a.n_variants && lane == 0u)
+                    if (!LINES && !RUNS && it.row_tail && (uint32_t)it.row + 1u < a.n_variants && lane == 0u)
                         nb[w] = (uint32_t)row_record<HAS_VIDX>(a, it.row + 1ull)[0];
                 }
             }
@@ -648,7 +626,10 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             if (t == kNoItem - 1ull) break;          // the loader found every range drained
             if (t != kNoItem) {                       // kNoItem: this storer has no item in this (last) step of a range
                 const Item it = desc_get_item(desc);
-                emit_item<HAS_VIDX, NT, true, LINES, BURST>(a, p, it, slab, lane);
+                if (RUNS)
+                    emit_run<NT>(a, p, it, slab, lane);
+                else
+                    emit_item<HAS_VIDX, NT, true, LINES, BURST>(a, p, it, slab, lane);
             }
             if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), step + 1u);
         }
@@ -700,124 +681,86 @@ bool gt_wide_lines_applicable(const EmitArgs &a)
            a.work_counters != nullptr;
 }
 
-hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream)
+hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream)
 {
     if (a.n_variants == 0) return hipSuccess;
+    if (a.work_counters == nullptr) return hipErrorInvalidValue;
     WideParams p;
     p.row_bytes = 4ull * a.kept_count + 1ull;
     p.total_bytes = (uint64_t)a.n_variants * p.row_bytes;
     p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 127ull);
-    p.dbg = nullptr;
-    {
-        // interleaved in one process (tools/probes/gpu_probe15.py, chr22 block): 8 ranges 2.058 ms, 4: 2.045, 2: 2.038, 1: 2.039
-        const char *er = getenv("PGENHIP_WIDE_RANGES");  // A/B: 1, 2, 4 or 8 item ranges (8 = one per XCD)
-        const int nr = er ? atoi(er) : 2;
-        p.n_ranges = nr == 1 || nr == 4 || nr == 8 ? (uint32_t)nr : 2u;
-    }
+    // interleaved in one process (profiles/r01_kernel_sweeps.md, chr22 block): 8 ranges 2.058 ms, 4: 2.045, 2: 2.038, 1: 2.039
+    p.n_ranges = t.wide_ranges == 1 || t.wide_ranges == 4 || t.wide_ranges == 8 ? (uint32_t)t.wide_ranges : 2u;
+    p.run_rows = 0u;
+    p.magic = 0u;
     // a row owns floor(S/16) or ceil(S/16) chunks (one more for row 0 with an unaligned pointer), and
     // its first span starts up to 63 chunks before them (1-KiB-aligned span grid)
     const uint64_t max_row_chunks = (p.row_bytes + 15ull) / 16ull + 1ull + 63ull;
     p.spans_per_row = (uint32_t)((max_row_chunks + kSpanChunks - 1ull) / kSpanChunks);
     p.n_items = (uint64_t)a.n_variants * p.spans_per_row;
 
-    const char *eb = getenv("PGENHIP_WIDE_BLOCKS_PER_CU");
-    const int blocks_per_cu = eb ? atoi(eb) : 8;
-    const char *en = getenv("PGENHIP_WIDE_NT");
-    const bool nt = en ? atoi(en) != 0 : true;
-    const char *es = getenv("PGENHIP_WIDE_STREAM");  // 0 = symmetric waves, 3 / 7 = storer waves per block
-    const int stream_ns = es ? atoi(es) : 7;  // default: 1 loader + 7 storer waves (interleaved A/B: profiles/r01_kernel_sweeps.md)
-    const char *ed = getenv("PGENHIP_WIDE_DYN");
-    const bool dyn = ed ? atoi(ed) != 0 : true;  // work queue on by default (interleaved A/B: +9 % on the chr22 block)
-    if ((stream_ns == 7 && dyn && a.work_counters) || a.line_off) {
-        const uint64_t need = (p.n_items + 6ull) / 7ull;
-        void (*dk)(EmitArgs, WideParams);
-        if (a.line_off) {
-            if (a.variant_idx) dk = nt ? gt_stream_dyn_kernel<7, true, true, true> : gt_stream_dyn_kernel<7, true, false, true>;
-            else dk = nt ? gt_stream_dyn_kernel<7, false, true, true> : gt_stream_dyn_kernel<7, false, false, true>;
-        } else {
-            if (a.variant_idx) dk = nt ? gt_stream_dyn_kernel<7, true, true> : gt_stream_dyn_kernel<7, true, false>;
-            else dk = nt ? gt_stream_dyn_kernel<7, false, true> : gt_stream_dyn_kernel<7, false, false>;
-            // plain store steps go out in bursts of 2 (text of both first, then both stores; in-process A/B: 1.995 vs 2.007 ms)
-            const char *ebu = getenv("PGENHIP_WIDE_BURST");
-            const int burst = ebu ? atoi(ebu) : 2;
-            if (!a.variant_idx && nt && burst == 1) dk = gt_stream_dyn_kernel<7, false, true, false, 1>;
-            if (!a.variant_idx && nt && burst == 4) dk = gt_stream_dyn_kernel<7, false, true, false, 4>;
-            if (!a.variant_idx && nt && burst == 8) dk = gt_stream_dyn_kernel<7, false, true, false, 8>;
-        }
-        // launch exactly what is resident (62 VGPRs -> 8 waves/SIMD -> four 512-thread blocks per CU; 25 KB of LDS
-        // each): blocks beyond that would only start when the queue is already empty.  Interleaved A/B on the chr22
-        // block: 2 blocks/CU 2.12 ms, 4 blocks/CU 2.00 ms (profiles/r01_kernel_sweeps.md)
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        if (eb && blocks_per_cu > 0) per_cu = blocks_per_cu;
-        const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
-        const uint32_t g = (uint32_t)(need < cap ? need : cap);
-        hipLaunchKernelGGL(dk, dim3(g), dim3(512), 0, stream, a, p);
-        if (a.line_off) return launch_copy_prefixes(a, num_cus, stream);  // the prefixes: disjoint bytes, same stream, any order
-        return hipGetLastError();
-    }
-    if (stream_ns == 3 || stream_ns == 7) {
-        const uint64_t need = (p.n_items + (uint64_t)stream_ns - 1ull) / (uint64_t)stream_ns;
-        const uint64_t cap = (uint64_t)num_cus * (uint64_t)blocks_per_cu;
-        const uint32_t g = (uint32_t)(need < cap ? need : cap);
-        void (*sk)(EmitArgs, WideParams);
-        if (stream_ns == 3) {
-            if (a.variant_idx) sk = nt ? gt_stream_kernel<3, true, true> : gt_stream_kernel<3, true, false>;
-            else sk = nt ? gt_stream_kernel<3, false, true> : gt_stream_kernel<3, false, false>;
-        } else {
-            if (a.variant_idx) sk = nt ? gt_stream_kernel<7, true, true> : gt_stream_kernel<7, true, false>;
-            else sk = nt ? gt_stream_kernel<7, false, true> : gt_stream_kernel<7, false, false>;
-        }
-        hipLaunchKernelGGL(sk, dim3(g), dim3(64 * (stream_ns + 1)), 0, stream, a, p);
-        return hipGetLastError();
-    }
-    const uint64_t blocks_needed = (p.n_items + kWaves - 1ull) / kWaves;
-    const uint64_t max_grid = (uint64_t)num_cus * (uint64_t)blocks_per_cu;
-    const uint32_t grid = (uint32_t)(blocks_needed < max_grid ? blocks_needed : max_grid);
-    void (*kern)(EmitArgs, WideParams);
-    if (a.variant_idx)
-        kern = nt ? gt_wide_kernel<true, true> : gt_wide_kernel<true, false>;
+    // 1 loader + 7 storer waves, nontemporal stores, plain store steps in bursts of 2 (text of both first, then both
+    // stores): the measured best of the round-1 A/Bs (3 storers, plain stores, bursts of 1/4/8: profiles/r01_kernel_sweeps.md)
+    const uint64_t need = (p.n_items + 6ull) / 7ull;
+    void (*dk)(EmitArgs, WideParams);
+    if (a.line_off)
+        dk = a.variant_idx ? gt_stream_dyn_kernel<7, true, true, true> : gt_stream_dyn_kernel<7, false, true, true>;
     else
-        kern = nt ? gt_wide_kernel<false, true> : gt_wide_kernel<false, false>;
-    // diagnostic only: per-wave start/end stamps dumped to /tmp/pgenhip_times.bin (never set in normal runs)
-    static const bool dbg_on = getenv("PGENHIP_DEBUG_TIMES") != nullptr;
-    if (dbg_on) {
-        const size_t words = (size_t)grid * kWaves * 3u;
-        uint64_t *d = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&d), words * 8u) == hipSuccess) {
-            (void)hipMemsetAsync(d, 0, words * 8u, stream);
-            p.dbg = d;
-            hipEvent_t e0, e1;
-            (void)hipEventCreate(&e0);
-            (void)hipEventCreate(&e1);
-            (void)hipStreamSynchronize(stream);
-            (void)hipEventRecord(e0, stream);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, p);
-            (void)hipEventRecord(e1, stream);
-            (void)hipStreamSynchronize(stream);
-            float ev_ms = 0.f;
-            (void)hipEventElapsedTime(&ev_ms, e0, e1);
-            uint64_t *h = static_cast<uint64_t *>(malloc(words * 8u));
-            (void)hipMemcpy(h, d, words * 8u, hipMemcpyDeviceToHost);
-            uint64_t tmin = ~0ull, tmax = 0ull;
-            for (size_t i = 0; i < words; i += 3) {
-                if (h[i] == 0) continue;
-                if (h[i] < tmin) tmin = h[i];
-                if (h[i + 1] > tmax) tmax = h[i + 1];
-            }
-            fprintf(stderr, "[pgenhip dbg] grid %u: hipEvent %.1f us, first-wave-start..last-wave-end %.1f us\n", grid, ev_ms * 1e3, (double)(tmax - tmin) / 100.0);
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-            if (FILE *f = fopen("/tmp/pgenhip_times.bin", "wb")) {
-                fwrite(h, 8, words, f);
-                fclose(f);
-            }
-            free(h);
-            (void)hipFree(d);
-            return hipGetLastError();
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, p);
+        dk = a.variant_idx ? gt_stream_dyn_kernel<7, true, true> : gt_stream_dyn_kernel<7, false, true>;
+    // launch exactly what is resident (62 VGPRs -> 8 waves/SIMD -> four 512-thread blocks per CU; 25 KB of LDS
+    // each): blocks beyond that would only start when the queue is already empty.  Interleaved A/B on the chr22
+    // block: 2 blocks/CU 2.12 ms, 4 blocks/CU 2.00 ms (profiles/r01_kernel_sweeps.md)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (t.wide_blocks_per_cu > 0) per_cu = t.wide_blocks_per_cu;
+    const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
+    const uint32_t g = (uint32_t)(need < cap ? need : cap);
+    hipLaunchKernelGGL(dk, dim3(g), dim3(512), 0, stream, a, p);
+    if (a.line_off) return launch_copy_prefixes(a, num_cus, stream);  // the prefixes: disjoint bytes, same stream, any order
+    return hipGetLastError();
+}
+
+// ---- RUNS mode: short rows, B rows per work item ---------------------------------------------------------
+static uint32_t run_rows_for(const EmitArgs &a)
+{
+    if (a.record_size == 0u) return 0u;
+    const uint32_t S = 4u * a.kept_count + 1u;
+    // one 16-B-per-lane load (+ the two shared extra pieces) covers the run's record bytes at any alignment + 1 byte:
+    // 15 + B*R + 1 <= 66 * 16; the run's chunks (+ up to 63 of lead) fit one 1 024-chunk span: B*S/16 + 2 + 63 <= 1 024
+    const uint32_t by_load = 1040u / a.record_size;
+    const uint32_t by_span = 15328u / S;
+    return by_load < by_span ? by_load : by_span;
+}
+
+bool gt_runs_applicable(const EmitArgs &a)
+{
+    // all samples kept, dense records AND dense text (both are then contiguous over a run of rows), rows of >= 33 bytes
+    // (a 16-byte chunk meets at most one '\n') and at least two rows per item (else the row-item kernel is the same thing)
+    return a.kept_idx == nullptr && a.line_off == nullptr && a.variant_idx == nullptr && a.sample_count >= 8u &&
+           (a.n_variants <= 1 || (a.out_stride == 4ull * a.kept_count + 1ull && a.record_stride == a.record_size)) &&
+           a.work_counters != nullptr && run_rows_for(a) >= 2u;
+}
+
+hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream)
+{
+    if (a.n_variants == 0) return hipSuccess;
+    if (!gt_runs_applicable(a)) return hipErrorInvalidValue;
+    WideParams p;
+    p.row_bytes = 4ull * a.kept_count + 1ull;
+    p.total_bytes = (uint64_t)a.n_variants * p.row_bytes;
+    p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 127ull);
+    p.n_ranges = t.wide_ranges == 1 || t.wide_ranges == 4 || t.wide_ranges == 8 ? (uint32_t)t.wide_ranges : 2u;
+    p.spans_per_row = 1u;
+    p.run_rows = t.runs_rows > 0 && (uint32_t)t.runs_rows < run_rows_for(a) ? (uint32_t)t.runs_rows : run_rows_for(a);
+    p.magic = (uint32_t)(0x100000000ull / p.row_bytes) + 1u;
+    p.n_items = ((uint64_t)a.n_variants + p.run_rows - 1ull) / p.run_rows;
+    const uint64_t need = (p.n_items + 6ull) / 7ull;
+    void (*dk)(EmitArgs, WideParams) = gt_stream_dyn_kernel<7, false, true, false, 2, true>;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (t.wide_blocks_per_cu > 0) per_cu = t.wide_blocks_per_cu;
+    const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
+    hipLaunchKernelGGL(dk, dim3((uint32_t)(need < cap ? need : cap)), dim3(512), 0, stream, a, p);
     return hipGetLastError();
 }
 

@@ -22,7 +22,20 @@ struct EmitArgs {
     const uint64_t *prefix_off;
     const uint64_t *line_off;
     uint64_t max_line_bytes;      // upper bound of any line's byte length (prefix + 4K + 1)
-    uint64_t *work_counters;      // device scratch owned by the ctx: 8 x 128-B-spaced work-queue heads + a block-exit counter at +1024 B; zero between launches (the last block out re-zeroes them)
+    uint64_t *work_counters;      // device scratch owned by the ctx, one block per launch in flight: 8 x 128-B-spaced work-queue heads + a block-exit counter at +1024 B; zero between launches (the last block out re-zeroes them)
+};
+
+// Launch-shape knobs, resolved ONCE per context: pgenhip_create sets the measured defaults below and
+// pgenhip_tune overrides one (tests force small grids to exercise ring reuse; A/B probes).  Nothing on the
+// launch path reads the process environment.
+struct Tuning {
+    int wide_blocks_per_cu = 0;    // stream kernel: 0 = what the occupancy API says is resident
+    int wide_ranges = 2;           // stream kernel: work-queue ranges (1, 2, 4 or 8)
+    int flat_blocks_per_cu = 64;   // flat kernel: grid cap
+    int scan_blocks_per_cu = 0;    // segment kernels: 0 = occupancy API
+    int scan_super = -1;           // three-segment gather kernel: -1 = in its measured band, 0 = never, 1 = wherever its ring allows
+    int pick_batch_bytes = 32768;  // short-record pick kernel: text per batch (one store drain per batch)
+    int runs_rows = 0;             // RUNS mode of the stream kernel: rows per work item (0 = as many as one wide load / one span holds)
 };
 
 // General row-tiled kernel: any alignment, any strides, list gather for kept subsets.
@@ -31,34 +44,31 @@ hipError_t launch_gt_rows(const EmitArgs &a, int num_cus, hipStream_t stream);
 // Dense all-samples stream kernel (K = N, out_stride == 4N+1): every lane owns one aligned
 // 16-byte chunk of the whole launch's output stream.
 bool gt_flat_applicable(const EmitArgs &a);
-hipError_t launch_gt_flat(const EmitArgs &a, int num_cus, hipStream_t stream);
+hipError_t launch_gt_flat(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream);
 
-// Same contract as the flat kernel, but a wave stages its span's record bytes with one wide
-// (16 B/lane) load into LDS and then issues 16 coalesced 1-KiB stores (rows >= 4 KiB of text).
+// Same contract as the flat kernel, but records are staged with wide (16 B/lane) loads through LDS by a loader
+// wave and storer waves issue 16 coalesced 1-KiB stores per work item (rows >= 4 KiB of text; needs work_counters).
 bool gt_wide_applicable(const EmitArgs &a);
 hipError_t launch_copy_prefixes(const EmitArgs &a, int num_cus, hipStream_t stream);  // full-line mode: prefix bytes of every line
 bool gt_wide_lines_applicable(const EmitArgs &a);  // full-line mode (line_off/prefix_off set) through the stream kernel
-hipError_t launch_gt_wide(const EmitArgs &a, int num_cus, hipStream_t stream);
+hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream);
+// RUNS mode of the same kernel for SHORT rows (8 <= N <= ~2000, dense records and dense text, no gather): a work item
+// is a run of consecutive rows — one wide load of their contiguous record bytes, their text as one contiguous run.
+bool gt_runs_applicable(const EmitArgs &a);
+hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream);
 
-// Stream-span kernel: like the wide stream kernel, but a work item is a 1-KiB-aligned 16-KiB span of the
-// output stream (crossing row ends), so every store step is a full 1 KiB (N >= 2048; needs work_counters).
-bool gt_span_applicable(const EmitArgs &a);
-hipError_t launch_gt_span(const EmitArgs &a, int num_cus, hipStream_t stream);
-
-// Kept-subset scan kernel: per-context keep bitmap (N bits, zero-padded to whole segments of
-// kScanSegmentSamples) + number of kept samples before each segment.
+// Kept-subset segment kernels: number of kept samples before each segment of kScanSegmentSamples samples.
 constexpr uint32_t kScanSegmentSamples = 16384u;
 struct ScanArgs {
-    const uint64_t *keep_words;  // device; n_segments * (kScanSegmentSamples / 64) words
     const uint32_t *seg_rank;    // device; n_segments + 1 entries
     uint32_t max_seg_count;      // most kept samples in any one segment
     uint32_t max_super_count;    // most kept samples in any aligned triple of segments (picks the three-segment gather kernel)
 };
-hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, int num_cus, hipStream_t stream);
+hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t, int num_cus, hipStream_t stream);
 
 // kept subsets on short records (N <= 4096): output-driven pick through the kept list, no compaction (gt_pick.hip)
 bool gt_pick_applicable(const EmitArgs &a);
-hipError_t launch_gt_pick(const EmitArgs &a, int num_cus, hipStream_t stream);
+hipError_t launch_gt_pick(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream);
 
 // Deterministic synthetic records (SURVEY.md §8d counter-based generator).
 hipError_t launch_synth_records(uint8_t *dst, uint64_t record_stride, uint32_t sample_count,

@@ -68,9 +68,9 @@ class GtEngine:
                 C.byref(self._ctx),
                 self.device,
                 self.sample_count,
-                arr.ctypes.data_as(C.c_void_p) if arr is not None else None,
+                arr.ctypes.data_as(C.c_void_p) if arr is not None and arr.size else None,
                 int(arr.size) if arr is not None else 0,
-                0,
+                _capi.CREATE_KEEP_LIST if arr is not None else 0,  # an empty list is a list, not "all samples"
             ),
             "pgenhip_create",
         )
@@ -105,6 +105,13 @@ class GtEngine:
 
     def use_own_stream(self) -> None:
         check(lib.pgenhip_reset_stream(self._ctx), "pgenhip_reset_stream")
+
+    def use_stream(self, stream: "torch.cuda.Stream") -> None:
+        check(lib.pgenhip_set_stream(self._ctx, C.c_void_p(stream.cuda_stream)), "pgenhip_set_stream")
+
+    def tune(self, knob: int, value: int) -> None:
+        """Launch-shape knob of this context (``_capi.KNOB_*``): tests force small grids, probes A/B."""
+        check(lib.pgenhip_tune(self._ctx, knob, value), "pgenhip_tune")
 
     def wait(self) -> None:
         check(lib.pgenhip_wait(self._ctx), "pgenhip_wait")

@@ -88,6 +88,7 @@ void pwrite_exact(int fd, const void *src, size_t bytes, uint64_t offset, const 
             if (errno == EINTR) continue;
             throw PfileError("write " + path + ": " + std::strerror(errno));
         }
+        if (w == 0) throw PfileError("write " + path + ": failed to write whole buffer");  // BufWriter::write_all -> WriteZero
         p += w;
         bytes -= (size_t)w;
         offset += (uint64_t)w;
@@ -336,8 +337,17 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     if (fd < 0) throw PfileError("create " + filename + ": " + std::strerror(errno));
     struct FdGuard {
         int fd;
-        ~FdGuard() { close(fd); }
+        ~FdGuard()
+        {
+            if (fd >= 0) close(fd);
+        }
     } guard{fd};
+    // a short or failed close (ENOSPC/EIO surfacing late) must not leave a truncated VCF behind an exit code 0
+    auto close_checked = [&] {
+        const int cfd = guard.fd;
+        guard.fd = -1;
+        if (close(cfd) != 0) throw PfileError("close " + filename + ": " + std::strerror(errno));
+    };
     pwrite_exact(fd, header.data(), header.size(), 0, filename);  // :139-146
 
     // ---- geometry of the body (:156-192): line j = prefix_j + K x "\tA/B" + "\n"
@@ -366,7 +376,10 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     st.samples_kept = K;
     st.header_bytes = header.size();
     st.body_bytes = file_off[V];
-    if (V == 0) return st;
+    if (V == 0) {
+        close_checked();
+        return st;
+    }
 
     int n_dev = 0;
     check(pgenhip_device_count(&n_dev), "pgenhip_device_count");
@@ -390,10 +403,10 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
 
     auto worker = [&](int g) {
         try {
-            // contiguous range of the kept-variant list per device, sizes differ by <= 1
-            const size_t base = V / (size_t)G, extra = V % (size_t)G;
-            const size_t begin = (size_t)g * base + std::min((size_t)g, extra);
-            const size_t end = begin + base + ((size_t)g < extra ? 1 : 0);
+            // contiguous range of the kept-variant list per device, sizes differ by <= 1: the one partitioner
+            uint64_t begin64 = 0, end64 = 0;
+            check(pgenhip_shard_range(V, (uint32_t)G, (uint32_t)g, &begin64, &end64), "pgenhip_shard_range");
+            const size_t begin = (size_t)begin64, end = (size_t)end64;
             if (begin == end) return;
             int pfd = open(pgen.c_str(), O_RDONLY);  // :149 (unbuffered on purpose, :150-152)
             if (pfd < 0) throw PfileError("open " + pgen + ": " + std::strerror(errno));
@@ -408,7 +421,9 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
             DeviceBuffers sets[2];
             for (int s = 0; s < n_sets; s++) {
                 DeviceBuffers &B = sets[s];
-                check(pgenhip_create(&B.ctx, g % n_use, N, all_samples ? nullptr : kept.data(), (uint32_t)K, 0), "pgenhip_create");
+                // a filter that kept NOBODY is an empty list, not "all samples": say so with the flag (kept.data() is NULL then)
+                check(pgenhip_create(&B.ctx, g % n_use, N, all_samples ? nullptr : kept.data(), (uint32_t)K,
+                                     all_samples ? 0u : PGENHIP_CREATE_KEEP_LIST), "pgenhip_create");
                 check(pgenhip_host_malloc_pinned(B.ctx, &B.h_rec, rec_bytes), "pinned records");
                 check(pgenhip_host_malloc_pinned(B.ctx, &B.h_blob, blob_bytes), "pinned prefixes");
                 check(pgenhip_host_malloc_pinned(B.ctx, &B.h_off, off_bytes), "pinned offsets");
@@ -569,6 +584,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     worker(0);
     for (auto &t : threads) t.join();
     if (!err.empty()) throw PfileError(err);
+    close_checked();
     st.seconds_body = now_s() - t_body;
     st.seconds_kernel = *std::max_element(kernel_s.begin(), kernel_s.end());
     return st;

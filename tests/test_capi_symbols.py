@@ -31,7 +31,7 @@ def test_symbol_exported(sym):
 
 
 def test_abi_version():
-    assert _capi.lib.pgenhip_abi_version() == 1
+    assert _capi.lib.pgenhip_abi_version() == 2
 
 
 def test_record_size_matches_oracle():
@@ -55,6 +55,22 @@ def test_parse_header_statuses():
         with pytest.raises(pgen_rs_amd.PgenHipError) as ei:
             pgen_rs_amd.parse_header(bad)
         assert ei.value.status == status
+
+
+def test_shard_range_is_the_one_partitioner():
+    from pgen_rs_amd.sharding import shard_range
+
+    b, e = C.c_uint64(), C.c_uint64()
+    assert _capi.lib.pgenhip_shard_range(10, 0, 0, C.byref(b), C.byref(e)) == _capi.ERR_BAD_ARG
+    assert _capi.lib.pgenhip_shard_range(10, 2, 2, C.byref(b), C.byref(e)) == _capi.ERR_BAD_ARG
+    assert [shard_range(1_000_000, 8, r) for r in range(8)] == [(125_000 * r, 125_000 * (r + 1)) for r in range(8)]
+    assert [shard_range(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+
+
+def test_no_getenv_on_the_launch_path():
+    # launch-shape knobs live in the ctx (pgenhip_tune); the library must not be steered by the process environment
+    for p in (REPO / "pgen_rs_amd" / "csrc").glob("*"):
+        assert "getenv" not in p.read_text(), p
 
 
 def test_strerror_covers_all_statuses():

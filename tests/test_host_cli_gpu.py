@@ -70,6 +70,19 @@ def test_reference_smoke_query_two_by_two(basic1, tmp_path):
     assert body[0].startswith(b"19\t266034\trs2312724\t") and body[1].startswith(b"19\t") and len(body[0].split(b"\t")) == 8 + 1 + 2
 
 
+def test_sample_filter_that_keeps_nobody(basic1, tmp_path):
+    """`--include-sam` keeping ZERO samples of a non-empty .pgen is an empty kept list, not
+    "all samples": every body line is the pvar columns + "GT" + '\n' (src/pfile.rs:171-190 with an empty
+    inner loop) and the header line ends in "FORMAT\t" + "" (:130-146)."""
+    out = tmp_path / "nobody.vcf"
+    p = run("filter", str(basic1), "--include-sam", 'IID == "nobody"', "--include-var", 'ALT=="G"', "--block-mib", "1", "-o", str(out))
+    assert p.returncode == 0, p.stderr
+    want = expected_vcf(basic1, var_pred=lambda r: r[b"ALT"] == b"G", sam_pred=lambda r: False)
+    got = out.read_bytes()
+    assert len(got) == len(want) and got == want
+    assert got.split(b"\n")[-2].endswith(b"\tGT")
+
+
 def test_no_variants_kept_and_default_output_name(basic1):
     p = run("filter", str(basic1), "--include-var", 'ID == "nothing"')
     assert p.returncode == 0, p.stderr
