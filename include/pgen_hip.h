@@ -59,7 +59,9 @@ typedef enum pgenhip_status {
     PGENHIP_ERR_BAD_FLAGS = -7,   /* src/pfile.rs:69 (byte 11 must be 0x40) */
     PGENHIP_ERR_NO_DEVICE = -8,   /* no HIP device / ordinal out of range */
     PGENHIP_ERR_TOO_LARGE = -9,   /* a size does not fit the kernel's index types */
-    PGENHIP_ERR_IO = -10          /* file read/write failed (ref: unwrap at src/pfile.rs:169-170) */
+    PGENHIP_ERR_IO = -10,         /* file read/write failed (ref: unwrap at src/pfile.rs:169-170) */
+    PGENHIP_ERR_BAD_INDEX = -11,  /* variable-width file: block offsets not ascending (src/pgen.rs:160-165), tables truncated, records overlap */
+    PGENHIP_ERR_COMPRESSED_RECORD = -12 /* variable-width file: a selected variant's record is not a plain 2-bit record (type != 0 or length != R) */
 } pgenhip_status;
 
 typedef struct pgenhip_ctx pgenhip_ctx;
@@ -85,6 +87,42 @@ uint64_t pgenhip_record_offset(uint64_t var_idx, uint32_t record_size);
  * extra.  The ONE partitioner: the C++ host's device threads, bench.py's ranks and the tests
  * all call this.  PGENHIP_ERR_BAD_ARG for world == 0 or rank >= world. */
 int pgenhip_shard_range(uint64_t n_variants, uint32_t world, uint32_t rank, uint64_t *begin, uint64_t *end);
+
+/* ---- variable-width storage modes: header and offset-table walk ----------------------
+ * The reference only VALIDATES these tables (src/pgen.rs, the dead `Pgen` type: header bits :52-67, block offsets
+ * :140-169, per-block type / length arrays :172-258) and its tool refuses every mode but 0x02 (src/pfile.rs:53).
+ * This slice turns the same tables into per-variant byte offsets so that the records such a file stores
+ * UNCOMPRESSED (record type 0: the mode-0x02 2-bit layout, length R) can be decoded in place by the kernels
+ * (pgenhip_decode_emit_at); any other record type is reported, never guessed at.  Allele-count arrays
+ * (allele_count_bytes != 0) are outside the slice: PGENHIP_ERR_BAD_FLAGS. */
+typedef struct pgenhip_vw_header {
+    uint32_t variant_count;           /* src/pgen.rs:42 */
+    uint32_t sample_count;            /* :47 */
+    uint8_t storage_mode;             /* :34 (0x10 = standard variable-width; the reference prints it, asserts nothing) */
+    uint8_t record_type_bits;         /* :61-65  4 or 8 */
+    uint8_t record_length_bytes;      /* :67     1..4 */
+    uint8_t allele_count_bytes;       /* :56 */
+    uint8_t provisional_ref_storage;  /* :57 */
+    uint8_t reserved[3];
+    uint64_t block_count;             /* :100-102  ceil(variant_count / 65 536) */
+    uint64_t main_header_body_offset; /* :112-114  12 + 8 * block_count */
+    uint64_t variant_records_offset;  /* :135-137  end of the type/length tables (type arrays rounded up per block, as the file stores them) */
+} pgenhip_vw_header;
+/* src/pgen.rs:21-98: BAD_MAGIC (:30), BAD_FLAGS (provisional_ref_storage != 1 :58, record storage mode >= 8 :64, allele counts present) */
+int pgenhip_vw_parse_header(const uint8_t header[12], pgenhip_vw_header *out);
+/* src/pgen.rs:140-258 turned into per-variant tables.  `index` = the file's bytes [12, variant_records_offset)
+ * (index_len of them); outputs are HOST arrays of variant_count entries: the record's type (4- or 8-bit value),
+ * its length and its byte offset in the file (block offset + lengths of the block's earlier records).
+ * PGENHIP_ERR_BAD_INDEX: table truncated, block offsets not strictly ascending (:160-165), a block's records
+ * run into the next block, or the first record starts inside the tables. */
+int pgenhip_vw_walk_index(const pgenhip_vw_header *h, const uint8_t *index, uint64_t index_len,
+                          uint8_t *record_type, uint32_t *record_len, uint64_t *record_off);
+/* The selected variants (variant_idx[0..n), or the first n when NULL) must all be plain 2-bit records:
+ * type 0 and length == R; writes their offsets to sel_off (n entries).  Else PGENHIP_ERR_COMPRESSED_RECORD
+ * (pgenhip_last_error_detail names the first offending variant and its type). */
+int pgenhip_vw_select_uncompressed(const uint8_t *record_type, const uint32_t *record_len, const uint64_t *record_off,
+                                   uint32_t variant_count, const uint32_t *variant_idx, uint32_t n,
+                                   uint32_t record_size, uint64_t *sel_off);
 
 /* ---- context ---------------------------------------------------------- */
 /* Binds a device and the kept-sample list (src/pfile.rs:128 sam_idx_rcs; the
@@ -133,6 +171,12 @@ uint64_t pgenhip_gt_row_bytes(const pgenhip_ctx *ctx);
 int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
                         const uint32_t *d_variant_idx, uint32_t n_variants,
                         void *d_out, uint64_t out_stride, uint32_t flags);
+
+/* Same, with the record of row j at d_base + d_record_off[j] (DEVICE array of n_variants byte offsets): the
+ * uncompressed records of a variable-width file staged to HBM as it lies on disk, or any other gapped layout.
+ * Every kernel family takes this gather (it replaces variant_idx * record_stride); RUNS needs dense records. */
+int pgenhip_decode_emit_at(pgenhip_ctx *ctx, const void *d_base, const uint64_t *d_record_off, uint32_t n_variants,
+                           void *d_out, uint64_t out_stride, uint32_t flags);
 
 /* Full VCF body lines (src/pfile.rs:156-192): line j = prefix bytes
  * d_prefix_blob[d_prefix_off[j] .. d_prefix_off[j+1]) (pvar columns + '\t' each,

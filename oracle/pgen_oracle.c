@@ -264,3 +264,16 @@ uint32_t pgo_synth_keep(uint32_t num_samples, uint64_t seed, uint32_t modulus,
     }
     return n;
 }
+
+/* src/pfile.rs:171-190 with the record of output row j at base + record_off[j] (byte offsets instead of the
+ * fixed-width offset formula of :165): the records of a variable-width file that are stored uncompressed. */
+int pgo_decode_emit_at(const uint8_t *base, const uint64_t *record_off, uint32_t n_variants,
+                       uint32_t num_samples, const uint32_t *kept_idx, uint32_t kept_count,
+                       uint8_t *out, uint64_t out_stride)
+{
+    for (uint32_t j = 0; j < n_variants; j++) {
+        int rc = pgo_decode_emit(base + record_off[j], 0, NULL, 1, num_samples, kept_idx, kept_count, out + (uint64_t)j * out_stride, out_stride);
+        if (rc) return rc;
+    }
+    return 0;
+}

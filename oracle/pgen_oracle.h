@@ -92,6 +92,40 @@ void pgo_synth_records(uint8_t *dst, uint64_t record_stride, uint32_t num_sample
 uint32_t pgo_synth_keep(uint32_t num_samples, uint64_t seed, uint32_t modulus,
                         uint32_t *kept_idx, uint32_t cap);
 
+/* ---- variable-width storage modes: header / offset-table walk (pgen_vw_oracle.c) ------------------------
+ * Restates the reference's `Pgen` validator, /root/reference/src/pgen.rs (dead code there: SURVEY.md F1). */
+typedef struct pgo_vw_header {
+    uint8_t storage_mode;            /* src/pgen.rs:34 */
+    uint32_t variant_count;          /* :42 */
+    uint32_t sample_count;           /* :47 */
+    uint8_t record_type_bits;        /* :61-65  4 or 8 */
+    uint8_t record_length_bytes;     /* :67     1..4 */
+    uint8_t allele_count_bytes;      /* :56 */
+    uint8_t provisional_ref_storage; /* :57 */
+} pgo_vw_header;
+/* :21-98  0 ok; -1 magic (:30); -2 provisional_ref_storage != 1 (:58); -3 invalid record storage mode (:64) */
+int pgo_vw_parse_header(const uint8_t hdr[12], pgo_vw_header *h);
+uint64_t pgo_vw_variant_block_count(const pgo_vw_header *h);     /* :100-102 */
+uint64_t pgo_vw_main_header_body_offset(const pgo_vw_header *h); /* :104-114 */
+uint64_t pgo_vw_main_header_body_size(const pgo_vw_header *h);   /* :116-133 */
+uint64_t pgo_vw_variant_records_offset(const pgo_vw_header *h);  /* :135-137 */
+/* :140-169  position behind the block offsets; -1 short file, -2 not strictly ascending */
+int64_t pgo_vw_check_variant_block_offsets(const pgo_vw_header *h, const uint8_t *file, uint64_t file_len, uint64_t offset);
+/* :172-258  position behind the last block (with the reference's last-block quirk); sets of distinct type values
+ * and distinct length bytes as 256-entry flag arrays; -1 short file */
+int64_t pgo_vw_check_main_header_body(const pgo_vw_header *h, const uint8_t *file, uint64_t file_len, uint64_t offset,
+                                      uint8_t types_seen[256], uint8_t length_bytes_seen[256]);
+/* NOT in the reference (parity unpinned): per-variant record type / length / file offset from the same tables.
+ * 0 ok; -1 short file; -2 block offsets not ascending; -3 a block's records overrun the next block's offset */
+int pgo_vw_index(const pgo_vw_header *h, const uint8_t *file, uint64_t file_len,
+                 uint8_t *types, uint32_t *lens, uint64_t *offs);
+
+/* src/pfile.rs:171-190 on records addressed by BYTE OFFSET (a variable-width file's uncompressed records,
+ * or any gapped layout): row j's record starts at base + record_off[j].  Otherwise as pgo_decode_emit. */
+int pgo_decode_emit_at(const uint8_t *base, const uint64_t *record_off, uint32_t n_variants,
+                       uint32_t num_samples, const uint32_t *kept_idx, uint32_t kept_count,
+                       uint8_t *out, uint64_t out_stride);
+
 #ifdef __cplusplus
 }
 #endif

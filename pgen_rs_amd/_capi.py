@@ -29,6 +29,8 @@ ERR_BAD_FLAGS = -7
 ERR_NO_DEVICE = -8
 ERR_TOO_LARGE = -9
 ERR_IO = -10
+ERR_BAD_INDEX = -11
+ERR_COMPRESSED_RECORD = -12
 
 KERNEL_AUTO = 0
 KERNEL_ROWS = 1
@@ -49,6 +51,16 @@ KNOB_SCAN_SUPER = 5
 KNOB_PICK_BATCH_BYTES = 6
 KNOB_RUNS_ROWS = 7
 
+
+
+class VwHeader(C.Structure):
+    """``pgenhip_vw_header`` (include/pgen_hip.h): header of a variable-width .pgen (src/pgen.rs:21-137)."""
+    _fields_ = [("variant_count", C.c_uint32), ("sample_count", C.c_uint32), ("storage_mode", C.c_uint8),
+                ("record_type_bits", C.c_uint8), ("record_length_bytes", C.c_uint8), ("allele_count_bytes", C.c_uint8),
+                ("provisional_ref_storage", C.c_uint8), ("reserved", C.c_uint8 * 3), ("block_count", C.c_uint64),
+                ("main_header_body_offset", C.c_uint64), ("variant_records_offset", C.c_uint64)]
+
+
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
@@ -64,6 +76,9 @@ PROTOTYPES = {
     "pgenhip_parse_header": (C.c_int, [C.c_char_p, u32p, u32p]),
     "pgenhip_record_offset": (C.c_uint64, [C.c_uint64, C.c_uint32]),
     "pgenhip_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]),
+    "pgenhip_vw_parse_header": (C.c_int, [C.c_char_p, C.POINTER(VwHeader)]),
+    "pgenhip_vw_walk_index": (C.c_int, [C.POINTER(VwHeader), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgenhip_vw_select_uncompressed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "pgenhip_create": (C.c_int, [C.POINTER(ctx_p), C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
     "pgenhip_destroy": (C.c_int, [ctx_p]),
     "pgenhip_set_stream": (C.c_int, [ctx_p, C.c_void_p]),
@@ -72,6 +87,7 @@ PROTOTYPES = {
     "pgenhip_kept_count": (C.c_uint32, [ctx_p]),
     "pgenhip_gt_row_bytes": (C.c_uint64, [ctx_p]),
     "pgenhip_decode_emit": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]),
+    "pgenhip_decode_emit_at": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]),
     "pgenhip_emit_lines": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
     "pgenhip_tune": (C.c_int, [ctx_p, C.c_uint32, C.c_int32]),
     "pgenhip_wait": (C.c_int, [ctx_p]),

@@ -89,6 +89,8 @@ const char *pgenhip_strerror(int status)
         case PGENHIP_ERR_NO_DEVICE: return "no usable HIP device";
         case PGENHIP_ERR_TOO_LARGE: return "size exceeds kernel index range";
         case PGENHIP_ERR_IO: return "I/O error";
+        case PGENHIP_ERR_BAD_INDEX: return "variable-width .pgen: bad block-offset / record-length tables";
+        case PGENHIP_ERR_COMPRESSED_RECORD: return "variable-width .pgen: selected record is not a plain 2-bit record";
         default: return "unknown status";
     }
 }
@@ -141,6 +143,100 @@ int pgenhip_shard_range(uint64_t n_variants, uint32_t world, uint32_t rank, uint
     const uint64_t base = n_variants / world, extra = n_variants % world;
     *begin = (uint64_t)rank * base + std::min<uint64_t>(rank, extra);
     *end = *begin + base + (rank < extra ? 1u : 0u);
+    return PGENHIP_OK;
+}
+
+// ---- variable-width storage modes (src/pgen.rs) ------------------------------------------------------------
+// src/pgen.rs:21-98
+int pgenhip_vw_parse_header(const uint8_t header[12], pgenhip_vw_header *out)
+{
+    if (!header || !out) return fail(PGENHIP_ERR_BAD_ARG, "NULL argument");
+    *out = pgenhip_vw_header{};
+    if (header[0] != 0x6C || header[1] != 0x1B) return fail(PGENHIP_ERR_BAD_MAGIC, "magic");  // :30
+    out->storage_mode = header[2];                                                             // :34
+    out->variant_count = (uint32_t)header[3] | (uint32_t)header[4] << 8 | (uint32_t)header[5] << 16 | (uint32_t)header[6] << 24;
+    out->sample_count = (uint32_t)header[7] | (uint32_t)header[8] << 8 | (uint32_t)header[9] << 16 | (uint32_t)header[10] << 24;
+    const uint8_t fmt = header[11];                       // :52
+    const uint8_t record_storage_mode = fmt & 0x0Fu;      // :55
+    out->allele_count_bytes = (uint8_t)((fmt >> 4) & 3u); // :56
+    out->provisional_ref_storage = (uint8_t)(fmt >> 6);   // :57
+    if (out->provisional_ref_storage != 1u) return fail(PGENHIP_ERR_BAD_FLAGS, "provisional_ref_storage != 1");  // :58
+    if (record_storage_mode >= 8u) return fail(PGENHIP_ERR_BAD_FLAGS, "invalid record storage mode");             // :61-65
+    out->record_type_bits = record_storage_mode < 4u ? 4u : 8u;
+    out->record_length_bytes = (uint8_t)(record_storage_mode % 4u + 1u);  // :67
+    if (out->allele_count_bytes != 0u) return fail(PGENHIP_ERR_BAD_FLAGS, "allele-count arrays are outside this slice");
+    constexpr uint64_t kBlock = 1ull << 16;               // :19
+    out->block_count = ((uint64_t)out->variant_count + kBlock - 1ull) / kBlock;  // :100-102
+    out->main_header_body_offset = 12ull + 8ull * out->block_count;              // :112-114
+    uint64_t body = 0;
+    for (uint64_t b = 0; b < out->block_count; b++) {
+        const uint64_t cnt = std::min<uint64_t>(kBlock, (uint64_t)out->variant_count - b * kBlock);
+        body += (cnt * out->record_type_bits + 7ull) / 8ull + cnt * out->record_length_bytes;  // per block, as the file stores it (:205-214)
+    }
+    out->variant_records_offset = out->main_header_body_offset + body;           // :135-137
+    return PGENHIP_OK;
+}
+
+// src/pgen.rs:140-258, producing per-variant tables instead of statistics
+int pgenhip_vw_walk_index(const pgenhip_vw_header *h, const uint8_t *index, uint64_t index_len,
+                          uint8_t *record_type, uint32_t *record_len, uint64_t *record_off)
+{
+    if (!h || (!index && index_len) || ((!record_type || !record_len || !record_off) && h && h->variant_count))
+        return fail(PGENHIP_ERR_BAD_ARG, "NULL argument");
+    if (h->variant_records_offset < 12ull || index_len < h->variant_records_offset - 12ull)
+        return fail(PGENHIP_ERR_BAD_INDEX, "index shorter than the header says");
+    constexpr uint64_t kBlock = 1ull << 16;
+    auto le = [&](uint64_t pos, uint32_t n) {  // little-endian value of n bytes at file offset 12 + pos
+        uint64_t v = 0;
+        for (uint32_t k = 0; k < n; k++) v |= (uint64_t)index[pos + k] << (8u * k);
+        return v;
+    };
+    uint64_t pos = 8ull * h->block_count;  // first block's tables, relative to file offset 12
+    uint64_t prev_end = h->variant_records_offset, prev_block_off = 0;
+    for (uint64_t b = 0; b < h->block_count; b++) {
+        const uint64_t block_off = le(8ull * b, 8);                                        // :147-152
+        if (b > 0 && !(prev_block_off < block_off)) return fail(PGENHIP_ERR_BAD_INDEX, "variant block offsets are not in ascending order");  // :160-165
+        if (block_off < prev_end) return fail(PGENHIP_ERR_BAD_INDEX, b ? "a block's records run into the next block" : "first record inside the tables");
+        const uint64_t first = b * kBlock;
+        const uint64_t cnt = std::min<uint64_t>(kBlock, (uint64_t)h->variant_count - first);
+        const uint64_t types_bytes = (cnt * h->record_type_bits + 7ull) / 8ull;            // :207-212
+        uint64_t off = block_off;
+        for (uint64_t i = 0; i < cnt; i++) {
+            uint8_t t;
+            if (h->record_type_bits == 4u) {
+                const uint8_t byte = index[pos + i / 2ull];                                 // :226-233: two types per byte, even variant low
+                t = (i & 1ull) ? (uint8_t)(byte >> 4) : (uint8_t)(byte & 0x0Fu);
+            } else {
+                t = index[pos + i];
+            }
+            const uint32_t len = (uint32_t)le(pos + types_bytes + i * h->record_length_bytes, h->record_length_bytes);  // :214, :236-240
+            record_type[first + i] = t;
+            record_len[first + i] = len;
+            record_off[first + i] = off;
+            off += len;
+        }
+        pos += types_bytes + cnt * h->record_length_bytes;
+        prev_end = off;
+        prev_block_off = block_off;
+    }
+    return PGENHIP_OK;
+}
+
+int pgenhip_vw_select_uncompressed(const uint8_t *record_type, const uint32_t *record_len, const uint64_t *record_off,
+                                   uint32_t variant_count, const uint32_t *variant_idx, uint32_t n,
+                                   uint32_t record_size, uint64_t *sel_off)
+{
+    if (n && (!record_type || !record_len || !record_off || !sel_off)) return fail(PGENHIP_ERR_BAD_ARG, "NULL argument");
+    for (uint32_t j = 0; j < n; j++) {
+        const uint32_t v = variant_idx ? variant_idx[j] : j;
+        if (v >= variant_count) return fail(PGENHIP_ERR_INDEX_RANGE, "variant index >= variant_count");
+        if (record_type[v] != 0u || record_len[v] != record_size) {
+            g_detail = "variant " + std::to_string(v) + ": record type " + std::to_string(record_type[v]) + ", length " + std::to_string(record_len[v]) +
+                       " (a plain 2-bit record has type 0 and length " + std::to_string(record_size) + ")";
+            return PGENHIP_ERR_COMPRESSED_RECORD;
+        }
+        sel_off[j] = record_off[v];
+    }
     return PGENHIP_OK;
 }
 
@@ -261,6 +357,7 @@ static int fill_args(pgenhip_ctx *ctx, EmitArgs &a, const void *d_records, uint6
     a.records = static_cast<const uint8_t *>(d_records);
     a.record_stride = record_stride;
     a.variant_idx = d_variant_idx;
+    a.record_off = nullptr;
     a.n_variants = n_variants;
     a.sample_count = ctx->sample_count;
     a.record_size = ctx->record_size;
@@ -306,15 +403,15 @@ static bool very_sparse(const pgenhip_ctx *ctx)
     return ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 300ull <= ctx->sample_count;
 }
 
-int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
-                        const uint32_t *d_variant_idx, uint32_t n_variants,
-                        void *d_out, uint64_t out_stride, uint32_t flags)
+static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride, const uint32_t *d_variant_idx,
+                            const uint64_t *d_record_off, uint32_t n_variants, void *d_out, uint64_t out_stride, uint32_t flags)
 {
     int rc = bind(ctx);
     if (rc) return rc;
     EmitArgs a;
-    rc = fill_args(ctx, a, d_records, record_stride, d_variant_idx, n_variants, d_out);
+    rc = fill_args(ctx, a, d_records, d_record_off ? (uint64_t)ctx->record_size : record_stride, d_variant_idx, n_variants, d_out);
     if (rc) return rc;
+    a.record_off = d_record_off;
     if (n_variants > 1 && out_stride < 4ull * ctx->kept_count + 1ull)
         return fail(PGENHIP_ERR_BAD_ARG, "out_stride < 4K+1");
     if (flags & ~PGENHIP_KERNEL_MASK) return fail(PGENHIP_ERR_BAD_ARG, "unknown decode_emit flag");
@@ -336,9 +433,13 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
                     LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
                 else
                     LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
-            } else if (gt_pick_applicable(a) && ctx->sample_count >= 400u && ctx->sample_count < 1400u)
-                // short rows (1.6-5.6 KiB of text): batches of rows as one run (gt_pick.hip with the identity for a table) beat both
-                // the flat kernel (N = 1000: 0.50 -> 0.58 of roofline) and the stream kernel's one-row work items (N = 1024: 0.49 -> 0.57)
+            } else if (gt_runs_applicable(a))
+                // short rows, dense records (8 <= N <= 1915): runs of rows as one work item, text staged through LDS in 4-KiB groups
+                // so that every 128-B line leaves whole: 0.68-0.71 of roofline from N = 100 to 1500 where the flat kernel had
+                // 0.42-0.56, the pick kernel 0.31-0.62 and the row-item stream kernel 0.51-0.65 (profiles/r02_kernel_sweeps.md)
+                LAUNCH_TRY(launch_gt_runs(a, t, ctx->num_cus, ctx->stream));
+            else if (gt_pick_applicable(a) && ctx->sample_count >= 400u && ctx->sample_count < 1400u)
+                // short rows that are gathered or padded (no contiguous runs): batches of rows through gt_pick.hip with the identity for a table
                 LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
             else if (gt_wide_applicable(a))
                 LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
@@ -374,6 +475,20 @@ int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record
         default:
             return fail(PGENHIP_ERR_BAD_ARG, "unknown kernel id");
     }
+}
+
+int pgenhip_decode_emit(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
+                        const uint32_t *d_variant_idx, uint32_t n_variants,
+                        void *d_out, uint64_t out_stride, uint32_t flags)
+{
+    return decode_emit_core(ctx, d_records, record_stride, d_variant_idx, nullptr, n_variants, d_out, out_stride, flags);
+}
+
+int pgenhip_decode_emit_at(pgenhip_ctx *ctx, const void *d_base, const uint64_t *d_record_off, uint32_t n_variants,
+                           void *d_out, uint64_t out_stride, uint32_t flags)
+{
+    if (n_variants && !d_record_off) return fail(PGENHIP_ERR_BAD_ARG, "d_record_off is NULL");
+    return decode_emit_core(ctx, d_base, 0, nullptr, d_record_off, n_variants, d_out, out_stride, flags);
 }
 
 int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,

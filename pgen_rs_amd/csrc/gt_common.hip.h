@@ -57,6 +57,14 @@ struct alignas(16) u32x4 {
     uint32_t x, y, z, w;
 };
 
+// Record of output row r when rows are gathered: byte offsets (uncompressed records of a variable-width .pgen,
+// src/pgen.rs's tables) or the kept-variant list (src/pfile.rs:165 with var_idx from the list).
+__device__ __forceinline__ const uint8_t *gathered_record(const EmitArgs &a, uint64_t r)
+{
+    if (a.record_off != nullptr) return a.records + a.record_off[r];
+    return a.records + (uint64_t)a.variant_idx[r] * a.record_stride;
+}
+
 // ---- all-samples text from a 16-bit record window ---------------------------------------------
 // 16 bytes of one row's GT text starting at segment offset q (q >= -15) cover samples
 // k0 = floor(q/4) .. k0+4 = 10 bits at bit 2*k0 of the record = record bytes b0 = floor(q/16)

@@ -41,8 +41,7 @@ struct FlatParams {
 template <bool HAS_VIDX>
 __device__ __forceinline__ const uint8_t *row_record(const EmitArgs &a, uint64_t r)
 {
-    const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[r] : r;
-    return a.records + src * a.record_stride;
+    return HAS_VIDX ? gathered_record(a, r) : a.records + r * a.record_stride;
 }
 
 // store one 16-byte chunk; NT = nontemporal hint (the text is written once and never re-read here)
@@ -247,7 +246,7 @@ hipError_t launch_gt_flat(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     p.step_rows = step / p.row_bytes;
     p.step_cols = step % p.row_bytes;
     const int wrap = p.row_bytes >= tile_bytes ? 0 : (p.row_bytes >= tile_bytes / 2u ? 1 : 2);
-    hipLaunchKernelGGL(kern[a.variant_idx ? 1 : 0][wrap], dim3(grid), dim3(kThreads), 0, stream, a, p);
+    hipLaunchKernelGGL(kern[gathered(a) ? 1 : 0][wrap], dim3(grid), dim3(kThreads), 0, stream, a, p);
     return hipGetLastError();
 }
 

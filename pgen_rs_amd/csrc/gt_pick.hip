@@ -135,8 +135,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
             buf[i] = v4u{0u, 0u, 0u, 0u};
             if ((uint32_t)i < B) {
                 const uint64_t row = min(row0 + (uint64_t)i, (uint64_t)a.n_variants - 1ull);  // rows past the end re-load the last row
-                const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
-                const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
+                const uint8_t *__restrict__ rec = HAS_VIDX ? gathered_record(a, row) : a.records + row * a.record_stride;
                 if (lane < p.pieces) __builtin_memcpy(&buf[i], rec + piece_off, 16);
             }
         }
@@ -269,13 +268,13 @@ hipError_t launch_gt_pick(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     void (*kern)(EmitArgs, PickParams);
     if (a.kept_idx == nullptr) {
         if (a.line_off)
-            kern = a.variant_idx ? gt_pick_kernel<true, true, true> : gt_pick_kernel<false, true, true>;
+            kern = gathered(a) ? gt_pick_kernel<true, true, true> : gt_pick_kernel<false, true, true>;
         else
-            kern = a.variant_idx ? gt_pick_kernel<true, false, true> : gt_pick_kernel<false, false, true>;
+            kern = gathered(a) ? gt_pick_kernel<true, false, true> : gt_pick_kernel<false, false, true>;
     } else if (a.line_off)
-        kern = a.variant_idx ? gt_pick_kernel<true, true, false> : gt_pick_kernel<false, true, false>;
+        kern = gathered(a) ? gt_pick_kernel<true, true, false> : gt_pick_kernel<false, true, false>;
     else
-        kern = a.variant_idx ? gt_pick_kernel<true, false, false> : gt_pick_kernel<false, false, false>;
+        kern = gathered(a) ? gt_pick_kernel<true, false, false> : gt_pick_kernel<false, false, false>;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     const uint64_t need = ((uint64_t)p.n_batches + kWaves - 1ull) / kWaves;

@@ -45,8 +45,7 @@ __global__ __launch_bounds__(kThreads) void gt_rows_kernel(EmitArgs a, uint32_t 
     for (uint64_t item = blockIdx.x; item < total_items; item += gridDim.x) {
         const uint32_t j = (uint32_t)(item / tiles_per_row);
         const uint32_t tile = (uint32_t)(item - (uint64_t)j * tiles_per_row);
-        const uint64_t row = a.variant_idx ? (uint64_t)a.variant_idx[j] : (uint64_t)j;
-        const uint8_t *__restrict__ rec = a.records + row * a.record_stride;
+        const uint8_t *__restrict__ rec = gathered(a) ? gathered_record(a, j) : a.records + (uint64_t)j * a.record_stride;
 
         uint64_t line_addr, prefix_pos = 0, prefix_len = 0;
         if (LINES) {

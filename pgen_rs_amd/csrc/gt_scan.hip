@@ -156,8 +156,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
     const uint32_t tail_shift = tail_b + 16u <= R ? 0u : min(tail_b - (R - 16u), 16u);
     auto load_sub = [&](uint64_t n, uint32_t q, v4u(&dst)[kTilesPerSeg]) {
         const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
-        const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
-        const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
+        const uint8_t *__restrict__ rec = HAS_VIDX ? gathered_record(a, row) : a.records + row * a.record_stride;
         const uint32_t tile0 = (ss * kSubSegs + q) * kTilesPerSeg;          // first record tile of the sub-segment
         const uint8_t *__restrict__ sub = rec + (uint64_t)tile0 * 1024u;    // scalar; tiles add an immediate
 #pragma unroll
@@ -290,8 +289,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     const uint32_t tail_shift = tail_b + 16u <= R ? 0u : min(tail_b - (R - 16u), 16u);
     auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg]) {
         const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
-        const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[row] : row;
-        const uint8_t *__restrict__ rec = a.records + src * a.record_stride;
+        const uint8_t *__restrict__ rec = HAS_VIDX ? gathered_record(a, row) : a.records + row * a.record_stride;
         const uint8_t *__restrict__ sub = rec + (uint64_t)tile0 * 1024u;
 #pragma unroll
         for (uint32_t t = 0; t < kTilesPerSeg; t++) {
@@ -376,7 +374,7 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
     const bool band = n_seg_eff >= kSubSegs && (uint64_t)a.kept_count * 125ull >= (uint64_t)a.sample_count;  // >= 0.8 % kept
     const bool super_kernel = sc.max_super_count <= kGatherMaxSegCodes && (t.scan_super >= 0 ? t.scan_super != 0 : band);
     if (super_kernel) {
-        void (*k3)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t) = a.variant_idx ? gt_scan_gather3_kernel<true> : gt_scan_gather3_kernel<false>;
+        void (*k3)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t) = gathered(a) ? gt_scan_gather3_kernel<true> : gt_scan_gather3_kernel<false>;
         const uint32_t n_super = (n_seg_eff + kSubSegs - 1u) / kSubSegs;
         uint64_t groups = (uint64_t)resident_blocks(k3, kThreads, num_cus, t) / n_super;
         if (groups < 1ull) groups = 1ull;
@@ -384,7 +382,7 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
         hipLaunchKernelGGL(k3, dim3((uint32_t)(groups * n_super)), dim3(kThreads), 0, stream, a, sc, n_seg_eff, n_super, (uint32_t)groups);
         return hipGetLastError();
     }
-    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t) = a.variant_idx ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
+    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t) = gathered(a) ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
     uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus, t) / n_seg_eff;  // floor: never a partial second round
     if (groups < 1ull) groups = 1ull;  // more segments than resident blocks (N > ~16 M samples): rounds are unavoidable
     if (groups > groups_needed) groups = groups_needed;

@@ -29,7 +29,7 @@ namespace {
 constexpr uint32_t kSpanChunks = 1024;  // chunks per work item: 16 stores x 64 lanes
 constexpr uint32_t kSlabBytes = 1088;   // 66 lanes x 16 B staged at most, rounded to 64
 constexpr uint32_t kSlabExtra = 16;     // stream kernels: +0 u8 = first record byte of row j+1 (for the chunk holding row j's '\n')
-// Item descriptors travel in their own LDS ring (kDescSlots = ring slots + 1 per storer, 64 B each), so the
+// Item descriptors travel in their own LDS ring (ring slots + 1 per storer, 64 B each), so the
 // loader can write them while it issues the loads, before it has to wait for the slab slot to be free:
 //   +8  u64 item index t (work-queue kernel; ~0 = no item, ~0-1 = launch is out of work)
 //   +16 u64 g0   +24 i64 c_first   +32 u64 row   +40 u32 cnt   +44 u32 lead   +48 i32 delta
@@ -52,8 +52,7 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 template <bool HAS_VIDX>
 __device__ __forceinline__ const uint8_t *row_record(const EmitArgs &a, uint64_t r)
 {
-    const uint64_t src = HAS_VIDX ? (uint64_t)a.variant_idx[r] : r;
-    return a.records + src * a.record_stride;
+    return HAS_VIDX ? gathered_record(a, r) : a.records + r * a.record_stride;
 }
 
 template <bool NT>
@@ -387,8 +386,20 @@ __device__ __forceinline__ u32x4 run_text16(const uint8_t *slab, uint32_t rec_of
     return gt_text16_from_window((uint32_t)h, (int64_t)pos);
 }
 
+// A run's text leaves in GROUPS of four store steps (256 chunks, 4 KiB) through the wave's LDS stage:
+//   A. every lane builds its four chunks as plain text of the row its first byte lies in (valid up to that row's
+//      '\n') and parks them in the stage (aligned ds_write_b128);
+//   B. the chunks of the group that hold a '\n' — one per row, their positions follow from S alone — are fixed
+//      up in ONE pass, lane i on the i-th of them: tail of row r from the stage, '\n', head of row r+1 from the
+//      slab, back into the stage.  (Done inside the store steps this merge runs in every step for two or three
+//      lanes — the whole wave pays for it 16 times per item instead of 4 times at N = 100; done as a separate
+//      16-byte store per row it leaves a hole in the step's store, and a 128-B line written in two pieces costs
+//      as much as half a KiB of whole lines: 0.31 of roofline at N = 100, measured.)
+//   C. the stage goes out as four 1-KiB stores of whole 128-B lines.
+constexpr uint32_t kStageBytes = 4096;
+
 template <bool NT>
-__device__ __forceinline__ void emit_run(const EmitArgs &a, const WideParams &p, const Item &it, const uint8_t *slab, uint32_t lane)
+__device__ __forceinline__ void emit_run(const EmitArgs &a, const WideParams &p, const Item &it, const uint8_t *slab, uint8_t *stage, uint32_t lane)
 {
     const uint32_t S = (uint32_t)p.row_bytes;
     const uint32_t R = a.record_size;
@@ -396,54 +407,92 @@ __device__ __forceinline__ void emit_run(const EmitArgs &a, const WideParams &p,
     const int32_t c_first = (int32_t)it.c_first;
     const uint32_t delta = (uint32_t)it.delta;
     const uint32_t nrows = (uint32_t)min((uint64_t)p.run_rows, (uint64_t)a.n_variants - it.row);
+    const uint32_t run_len = nrows * S;
+    const bool has_next_run = it.row + (uint64_t)nrows < (uint64_t)a.n_variants;
     uint8_t *const span_ptr = chunk0 + (it.g0 - it.lead) * 16ull + lane * 16u;  // lane's chunk in step 0
     const uint32_t end = it.lead + it.cnt;
-    // ---- store steps: every chunk that lies wholly inside one row's GT text
-    for (uint32_t u = 0; u * 64u < end; u++) {
-        const uint32_t i = u * 64u + lane - it.lead;                  // chunk of this item (wraps to huge before `lead`)
-        const int32_t o_s = c_first + 16 * (int32_t)i;
-        const uint32_t o = (uint32_t)max(o_s, 0);
-        uint32_t r = __umulhi(o, p.magic);
-        uint32_t rs = __umul24(r, S);
-        if (rs > o) {
-            r--;
-            rs -= S;
-        }
-        const uint32_t pos = o - rs;
-        const bool plain = i < it.cnt && o_s >= 0 && pos + 17u <= S;  // bytes pos .. pos+15 are GT text of row r
-        if (plain) store_chunk<NT>(span_ptr + u * 1024u, run_text16(slab, delta + __umul24(min(r, nrows - 1u), R), pos));
-    }
-    // ---- the '\n' chunks, one per row: lane rr builds row rr's
-    for (uint32_t rr = lane; rr < nrows; rr += 64u) {
-        const uint32_t e = rr * S + S - 1u;                            // run offset of the row's '\n'
-        const uint32_t i = (uint32_t)((int32_t)e - c_first) >> 4;      // its chunk (e >= 32 > c_first)
-        const uint32_t nl = (uint32_t)((int32_t)e - c_first) & 15u;    // its byte inside that chunk
-        const uint32_t pos = S - 1u - nl;                              // row byte of the chunk's first byte (>= 17)
-        const uint32_t rec_off = delta + rr * R;
-        const u32x4 x = run_text16(slab, rec_off, pos);
-        const bool has_next = it.row + rr + 1ull < (uint64_t)a.n_variants;
-        u32x4 y = {0u, 0u, 0u, 0u};
-        if (nl < 15u && has_next) y = gt_text16_from_window((uint32_t)slab[rec_off + R] << 8, -(int64_t)nl - 1);  // record byte -1 (none) and byte 0 of row rr+1
-        const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-        const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
-        uint32_t os[4];
+    // the stream's very last chunk ends at the last '\n': if that is not its 16th byte the chunk is written byte-wise (phase B)
+    const uint32_t e_last = run_len - 1u;
+    const bool ragged_end = !has_next_run && (((uint32_t)((int32_t)e_last - c_first)) & 15u) != 15u;
+    const uint32_t cnt_whole = it.cnt - (ragged_end ? 1u : 0u);
+    v4u *const st = reinterpret_cast<v4u *>(stage);
+    for (uint32_t g = 0; g * 256u < end; g++) {
+        // ---- A: plain text of every chunk of the group
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int32_t nb = (int32_t)nl - 4 * m;  // bytes of dword m taken from row rr
-            const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
-            uint32_t d = (xs[m] & mask) | (ys[m] & ~mask);
-            if (nb >= 0 && nb < 4) d = (d & ~(0xFFu << (8 * nb))) | (0x0Au << (8 * nb));
-            os[m] = d;
+        for (uint32_t s4 = 0; s4 < 4u; s4++) {
+            const uint32_t idx = g * 256u + s4 * 64u + lane;
+            if (g * 256u + s4 * 64u >= end) break;
+            const int32_t o_s = c_first + 16 * (int32_t)(idx - it.lead);
+            const uint32_t o = (uint32_t)min(max(o_s, 0), (int32_t)run_len - 1);  // lanes outside the item build a harmless chunk
+            uint32_t r = __umulhi(o, p.magic);
+            uint32_t rs = __umul24(r, S);
+            if (rs > o) {
+                r--;
+                rs -= S;
+            }
+            const u32x4 x = run_text16(slab, delta + __umul24(r, R), o - rs);
+            st[s4 * 64u + lane] = v4u{x.x, x.y, x.z, x.w};
         }
-        uint8_t *const dst = chunk0 + (it.g0 + i) * 16ull;
-        if (has_next || nl == 15u) {
-            store_chunk<NT>(dst, u32x4{os[0], os[1], os[2], os[3]});
-        } else {
-            // last row of the whole stream: the chunk ends at the '\n', bytes behind it are not ours
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- B: the group's '\n' chunks.  Chunks [i_lo, i_hi) of the item are in the group; row rr's '\n' sits at run
+        // offset e = rr * S + S - 1, and e >= lo  <=>  rr >= floor(lo / S)
+        const uint32_t i_lo = g * 256u > it.lead ? g * 256u - it.lead : 0u;
+        const uint32_t i_hi = min(it.cnt, g * 256u + 256u - it.lead);
+        const uint32_t lo = (uint32_t)max(c_first + 16 * (int32_t)i_lo, 0);
+        const uint32_t hi = (uint32_t)(c_first + 16 * (int32_t)i_hi);   // > 0: the group holds at least one chunk of the item
+        // (wave-uniform: s_mul_hi_u32 by the host's reciprocal instead of a division sequence per group)
+        uint32_t rr_lo = __umulhi(lo, p.magic);
+        if (rr_lo * S > lo) rr_lo--;
+        uint32_t rr_hi = __umulhi(hi, p.magic);
+        if (rr_hi * S > hi) rr_hi--;
+        rr_hi = min(rr_hi, nrows);
+        for (uint32_t rr = rr_lo + lane; rr < rr_hi; rr += 64u) {
+            const uint32_t e = rr * S + S - 1u;                            // run offset of the row's '\n'
+            const uint32_t i = (uint32_t)((int32_t)e - c_first) >> 4;      // its chunk (e >= 32 > c_first)
+            const uint32_t nl = (uint32_t)((int32_t)e - c_first) & 15u;    // its byte inside that chunk
+            const uint32_t slot = i + it.lead - g * 256u;                  // 0 .. 255
+            const v4u x = st[slot];
+            const bool has_next = rr + 1u < nrows || has_next_run;
+            u32x4 y = {0u, 0u, 0u, 0u};
+            if (nl < 15u && has_next) y = gt_text16_from_window((uint32_t)slab[delta + (rr + 1u) * R] << 8, -(int64_t)nl - 1);  // record byte -1 (none) and byte 0 of row rr+1
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+            const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
+            uint32_t os[4];
 #pragma unroll
-            for (int b = 0; b < 16; b++)
-                if ((uint32_t)b <= nl) dst[b] = (uint8_t)(os[b >> 2] >> (8 * (b & 3)));
+            for (int m = 0; m < 4; m++) {
+                const int32_t nb = (int32_t)nl - 4 * m;  // bytes of dword m taken from row rr
+                const uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+                uint32_t d = (xs[m] & mask) | (ys[m] & ~mask);
+                if (nb >= 0 && nb < 4) d = (d & ~(0xFFu << (8 * nb))) | (0x0Au << (8 * nb));
+                os[m] = d;
+            }
+            if (has_next || nl == 15u) {
+                st[slot] = v4u{os[0], os[1], os[2], os[3]};
+            } else {
+                // last row of the whole stream: the chunk ends at the '\n', the bytes behind it are not ours
+                uint8_t *const dst = chunk0 + (it.g0 + i) * 16ull;
+#pragma unroll
+                for (int b = 0; b < 16; b++)
+                    if ((uint32_t)b <= nl) dst[b] = (uint8_t)(os[b >> 2] >> (8 * (b & 3)));
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- C: four 1-KiB stores
+#pragma unroll
+        for (uint32_t s4 = 0; s4 < 4u; s4++) {
+            const uint32_t u = g * 4u + s4;
+            if (u * 64u >= end) break;
+            const uint32_t i = u * 64u + lane - it.lead;  // wraps to huge before `lead`
+            const v4u v = st[s4 * 64u + lane];
+            if (i < cnt_whole && !(c_first < 0 && i == 0u)) store_chunk<NT>(span_ptr + u * 1024u, u32x4{v.x, v.y, v.z, v.w});
+        }
+        // the stage is rewritten by the next group: this group's reads must have returned first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     // ---- run 0 with an unaligned output pointer: the bytes of chunk 0 that belong to the stream (all in row 0's text: S >= 33)
     if (c_first < 0 && it.cnt != 0u && lane < 16u && (int32_t)lane + c_first >= 0) {
@@ -465,7 +514,7 @@ __device__ __forceinline__ void emit_run(const EmitArgs &a, const WideParams &p,
 // (Round 1 also carried a symmetric-wave kernel and a static-partition role kernel as A/B partners:
 // 0.54 and 0.61 of roofline against this kernel's 0.66-0.73 on the chr22 block, profiles/r01_*; removed.)
 constexpr int kRingSlots = 3;
-constexpr int kDescSlots = kRingSlots + 1;  // slot s % 4 was last read in step s-4, whose `done` the loader saw in step s-1
+// descriptor ring: ring slots + 1 (slot s % 4 was last read in step s-4, whose `done` the loader saw in step s-1)
 
 // WORK QUEUE instead of a static item partition: only 4 of these 512-thread blocks fit on a CU, so
 // a static grid-stride split of a big grid runs in rounds and the last, partly filled round is a
@@ -479,13 +528,17 @@ constexpr int kDescSlots = kRingSlots + 1;  // slot s % 4 was last read in step 
 template <int NS, bool HAS_VIDX, bool NT, bool LINES = false, int BURST = 2, bool RUNS = false>
 __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a, WideParams p)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][kRingSlots][kSlabBytes + kSlabExtra];
-    __shared__ __attribute__((aligned(16))) uint8_t s_desc[NS][kDescSlots][kDescBytes];
-    __shared__ uint32_t s_full[NS][kRingSlots];
-    __shared__ uint32_t s_done[NS][kRingSlots];
+    // RUNS mode trades one slab slot per storer for the storers' 4-KiB text stages (LDS per block: 25 KB -> 45 KB)
+    constexpr int RS = RUNS ? 2 : kRingSlots;
+    constexpr int DS = RS + 1;
+    __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][RS][kSlabBytes + kSlabExtra];
+    __shared__ __attribute__((aligned(16))) uint8_t s_desc[NS][DS][kDescBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[RUNS ? NS : 1][RUNS ? kStageBytes : 16u];
+    __shared__ uint32_t s_full[NS][RS];
+    __shared__ uint32_t s_done[NS][RS];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x < NS * kRingSlots) {
+    if (threadIdx.x < NS * RS) {
         (&s_full[0][0])[threadIdx.x] = 0u;
         (&s_done[0][0])[threadIdx.x] = 0u;
     }
@@ -523,7 +576,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                 if (drained < nr) got = sgpr64(issue_claim(range));
             }
             const uint64_t t_end = t0 == kNoItem ? 0ull : min(t0 + NS, min(((uint64_t)range + 1ull) * per_range, p.n_items));
-            const uint32_t slot = (uint32_t)(step % kRingSlots);
+            const uint32_t slot = (uint32_t)(step % RS);
             // in0[w]: pieces 0-63 of item w; `ext`: pieces 64 and 65 of ALL items, item w in lanes 2w and 2w+1, fetched
             // by ONE load after the item loop (seven masked loads into one register quad would each wait for the
             // one before: the compiler orders writes to a register it cannot prove lane-disjoint)
@@ -562,7 +615,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                 // descriptor first (its ring has one slot more than the slab ring, so no wait is needed here)
                 if ((uint32_t)w >= n_here) {
                     // ~0-1 = "launch is out of work", ~0 = no item for this storer in this (last) step of a range
-                    if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], Item{}, t0 == kNoItem ? kNoItem - 1ull : kNoItem);
+                    if (lane == 0u) desc_put_item(s_desc[w][step % DS], Item{}, t0 == kNoItem ? kNoItem - 1ull : kNoItem);
                 } else {
                     uint64_t row_start = 0ull;
                     if (LINES) {
@@ -576,7 +629,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
                         k_it = 0u;
                         j_it++;
                     }
-                    if (lane == 0u) desc_put_item(s_desc[w][step % kDescSlots], it, t0 + (uint64_t)w);
+                    if (lane == 0u) desc_put_item(s_desc[w][step % DS], it, t0 + (uint64_t)w);
                     if (lane < it.n_load) in0[w] = *reinterpret_cast<const v4u *>(it.base + lane * 16u);
                     if ((lane >> 1) == (uint32_t)w) {
                         ext_addr = it.base + (64u + (lane & 1u)) * 16u;
@@ -591,8 +644,8 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
             if (t0 != kNoItem) pending = issue_claim(range);  // for the next step; read at the top of the loop
 #pragma unroll
             for (int w = 0; w < NS; w++) {
-                if (step >= kRingSlots) {
-                    const uint32_t want = step - kRingSlots + 1u;
+                if (step >= (uint32_t)RS) {
+                    const uint32_t want = step - (uint32_t)RS + 1u;
                     while (lds_flag_read(lds_offset(&s_done[w][slot])) != want) __builtin_amdgcn_s_sleep(1);
                 }
                 uint8_t *slab = slabs[w][slot];
@@ -617,17 +670,17 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
         // ------------------------------ storer waves -----------------------------
         const uint32_t w = wave - 1u;
         for (uint32_t step = 0;; step++) {  // 32-bit: a block that ran 2^32 steps would have written > 2^47 bytes
-            const uint32_t slot = step % kRingSlots;
+            const uint32_t slot = step % RS;
             while (lds_flag_read(lds_offset(&s_full[w][slot])) != step + 1u) __builtin_amdgcn_s_sleep(1);
             const uint8_t *slab = slabs[w][slot];
-            const uint8_t *desc = s_desc[w][step % kDescSlots];
+            const uint8_t *desc = s_desc[w][step % DS];
             uint64_t t = *reinterpret_cast<const uint64_t *>(desc + 8u);
             t = sgpr64(t);
             if (t == kNoItem - 1ull) break;          // the loader found every range drained
             if (t != kNoItem) {                       // kNoItem: this storer has no item in this (last) step of a range
                 const Item it = desc_get_item(desc);
                 if (RUNS)
-                    emit_run<NT>(a, p, it, slab, lane);
+                    emit_run<NT>(a, p, it, slab, s_stage[RUNS ? w : 0u], lane);
                 else
                     emit_item<HAS_VIDX, NT, true, LINES, BURST>(a, p, it, slab, lane);
             }
@@ -704,9 +757,9 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     const uint64_t need = (p.n_items + 6ull) / 7ull;
     void (*dk)(EmitArgs, WideParams);
     if (a.line_off)
-        dk = a.variant_idx ? gt_stream_dyn_kernel<7, true, true, true> : gt_stream_dyn_kernel<7, false, true, true>;
+        dk = gathered(a) ? gt_stream_dyn_kernel<7, true, true, true> : gt_stream_dyn_kernel<7, false, true, true>;
     else
-        dk = a.variant_idx ? gt_stream_dyn_kernel<7, true, true> : gt_stream_dyn_kernel<7, false, true>;
+        dk = gathered(a) ? gt_stream_dyn_kernel<7, true, true> : gt_stream_dyn_kernel<7, false, true>;
     // launch exactly what is resident (62 VGPRs -> 8 waves/SIMD -> four 512-thread blocks per CU; 25 KB of LDS
     // each): blocks beyond that would only start when the queue is already empty.  Interleaved A/B on the chr22
     // block: 2 blocks/CU 2.12 ms, 4 blocks/CU 2.00 ms (profiles/r01_kernel_sweeps.md)
@@ -736,7 +789,7 @@ bool gt_runs_applicable(const EmitArgs &a)
 {
     // all samples kept, dense records AND dense text (both are then contiguous over a run of rows), rows of >= 33 bytes
     // (a 16-byte chunk meets at most one '\n') and at least two rows per item (else the row-item kernel is the same thing)
-    return a.kept_idx == nullptr && a.line_off == nullptr && a.variant_idx == nullptr && a.sample_count >= 8u &&
+    return a.kept_idx == nullptr && a.line_off == nullptr && !gathered(a) && a.sample_count >= 8u &&
            (a.n_variants <= 1 || (a.out_stride == 4ull * a.kept_count + 1ull && a.record_stride == a.record_size)) &&
            a.work_counters != nullptr && run_rows_for(a) >= 2u;
 }

@@ -10,6 +10,8 @@ struct EmitArgs {
     const uint8_t *records;       // device; row r at records + r*record_stride
     uint64_t record_stride;
     const uint32_t *variant_idx;  // device or nullptr (identity)
+    const uint64_t *record_off;   // device or nullptr; when set, row j's record starts at records + record_off[j] (byte offsets:
+                                  // uncompressed records of a variable-width .pgen) and variant_idx / record_stride are not used
     uint32_t n_variants;
     uint32_t sample_count;        // N
     uint32_t record_size;         // R = ceil(N/4)
@@ -37,6 +39,9 @@ struct Tuning {
     int pick_batch_bytes = 32768;  // short-record pick kernel: text per batch (one store drain per batch)
     int runs_rows = 0;             // RUNS mode of the stream kernel: rows per work item (0 = as many as one wide load / one span holds)
 };
+
+// rows are gathered (variant list or byte offsets): the HAS_VIDX instantiations
+__host__ __device__ inline bool gathered(const EmitArgs &a) { return a.variant_idx != nullptr || a.record_off != nullptr; }
 
 // General row-tiled kernel: any alignment, any strides, list gather for kept subsets.
 hipError_t launch_gt_rows(const EmitArgs &a, int num_cus, hipStream_t stream);

@@ -270,6 +270,42 @@ def test_pick_kernel_short_records(n):
                 raise AssertionError(f"n={n} mask={label} v={v} off={out_offset}: {bad.size} bytes differ, first at {bad[:6]}")
 
 
+@pytest.mark.parametrize("n", [8, 9, 10, 11, 33, 61, 100, 255, 256, 300, 301, 302, 303, 500, 1000, 1024, 1399, 1915])
+def test_runs_kernel_short_rows(n):
+    """RUNS mode of the stream kernel (short rows: a work item is a run of consecutive rows; the '\n' chunks of a
+    run are written in a separate pass).  N from 8 (33-byte rows) up to the largest N with two rows per item,
+    incl. the reference's own dataset shape N = 300 and N % 4 in {0,1,2,3}; V = 1, V < one run, V not a multiple
+    of the run, many runs per block (ring re-use, queue stealing); unaligned output AND record pointers (every
+    phase of the first chunk and of the wide load); forced short runs (2, 3 rows); sentinels around the output."""
+    rng = np.random.default_rng(3300 + n)
+    r = oracle.variant_record_size(n)
+    for v, out_off, rec_off, rows_knob in ((1, 0, 0, 0), (2, 1, 3, 0), (7, 15, 1, 2), (64, 16, 15, 3), (1031, 5, 7, 0), (20_011, 127, 0, 0)):
+        recs = rng.integers(0, 256, size=rec_off + v * r, dtype=np.uint8)
+        want = oracle.decode_emit(recs[rec_off:], v, n).reshape(v, -1)
+        tune = {_capi.KNOB_RUNS_ROWS: rows_knob}
+        if v > 10_000:
+            tune[_capi.KNOB_WIDE_BLOCKS_PER_CU] = 1
+        got, _ = run_engine(recs, v, n, kernel=_capi.KERNEL_RUNS, out_offset=out_off, records_offset=rec_off, tune=tune)
+        exp = expect_buffer(want, v, n, 4 * n + 1, out_off, got.size)
+        if not (got == exp).all():
+            bad = np.flatnonzero(got != exp)
+            raise AssertionError(f"n={n} v={v} out_off={out_off} rec_off={rec_off} rows={rows_knob}: {bad.size} bytes differ, first at {bad[:8]}")
+
+
+def test_runs_kernel_refuses_what_it_cannot_do():
+    with pgen_rs_amd.GtEngine(300, device=0) as eng:
+        recs = torch.zeros(10 * 80, dtype=torch.uint8, device=DEV)
+        out = torch.zeros(10 * 1201, dtype=torch.uint8, device=DEV)
+        with pytest.raises(pgen_rs_amd.PgenHipError):   # padded record stride: the run's records are not contiguous
+            eng.decode_emit(recs, 10, record_stride=80, out=out, kernel=_capi.KERNEL_RUNS)
+        vidx = torch.arange(10, dtype=torch.int32, device=DEV)
+        with pytest.raises(pgen_rs_amd.PgenHipError):   # variant gather
+            eng.decode_emit(recs, 10, variant_idx=vidx, out=out, kernel=_capi.KERNEL_RUNS)
+    with pgen_rs_amd.GtEngine(2504, device=0) as eng:   # one row per item: that is the row-item kernel
+        with pytest.raises(pgen_rs_amd.PgenHipError):
+            eng.decode_emit(torch.zeros(626 * 4, dtype=torch.uint8, device=DEV), 4, kernel=_capi.KERNEL_RUNS)
+
+
 def test_work_queue_heads_alternate_across_launches():
     """One context, many launches: the last block of a work-queue launch re-zeroes its block of queue heads and
     every launch takes the next block of the ring (more launches than the ring has blocks).  Interleave
