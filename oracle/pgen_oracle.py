@@ -42,7 +42,28 @@ def _load() -> C.CDLL:
     h.pgo_synth_records.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int]
     h.pgo_synth_keep.restype = C.c_uint32
     h.pgo_synth_keep.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_uint32]
+    # variable-width header walk (pgen_vw_oracle.c)
+    h.pgo_vw_parse_header.restype = C.c_int
+    h.pgo_vw_parse_header.argtypes = [C.c_char_p, C.POINTER(VwHeader)]
+    for name in ("pgo_vw_variant_block_count", "pgo_vw_main_header_body_offset", "pgo_vw_main_header_body_size", "pgo_vw_variant_records_offset"):
+        getattr(h, name).restype = C.c_uint64
+        getattr(h, name).argtypes = [C.POINTER(VwHeader)]
+    h.pgo_vw_check_variant_block_offsets.restype = C.c_int64
+    h.pgo_vw_check_variant_block_offsets.argtypes = [C.POINTER(VwHeader), vp, C.c_uint64, C.c_uint64]
+    h.pgo_vw_check_main_header_body.restype = C.c_int64
+    h.pgo_vw_check_main_header_body.argtypes = [C.POINTER(VwHeader), vp, C.c_uint64, C.c_uint64, vp, vp]
+    h.pgo_vw_index.restype = C.c_int
+    h.pgo_vw_index.argtypes = [C.POINTER(VwHeader), vp, C.c_uint64, vp, vp, vp]
+    h.pgo_decode_emit_at.restype = C.c_int
+    h.pgo_decode_emit_at.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64]
     return h
+
+
+class VwHeader(C.Structure):
+    """``pgo_vw_header``: what src/pgen.rs:21-98 parses out of the 12 header bytes."""
+    _fields_ = [("storage_mode", C.c_uint8), ("variant_count", C.c_uint32), ("sample_count", C.c_uint32),
+                ("record_type_bits", C.c_uint8), ("record_length_bytes", C.c_uint8), ("allele_count_bytes", C.c_uint8),
+                ("provisional_ref_storage", C.c_uint8)]
 
 
 lib = _load()
@@ -149,3 +170,54 @@ def synth_keep(num_samples: int, seed: int = 0x4D41534B, modulus: int = 100) -> 
     buf = np.zeros(max(num_samples, 1), dtype=np.uint32)
     n = lib.pgo_synth_keep(num_samples, seed, modulus, _vp(buf), num_samples)
     return buf[:n].copy()
+
+
+# ---- variable-width storage modes (src/pgen.rs) -------------------------------------------------------------
+def vw_parse_header(hdr: bytes):
+    """-> (rc, VwHeader); rc as pgo_vw_parse_header (0 ok, -1 magic, -2 provisional ref, -3 record storage mode)."""
+    h = VwHeader()
+    rc = lib.pgo_vw_parse_header(bytes(hdr[:12]), C.byref(h))
+    return int(rc), h
+
+
+def vw_geometry(h: VwHeader) -> dict:
+    return {
+        "block_count": int(lib.pgo_vw_variant_block_count(C.byref(h))),
+        "main_header_body_offset": int(lib.pgo_vw_main_header_body_offset(C.byref(h))),
+        "main_header_body_size": int(lib.pgo_vw_main_header_body_size(C.byref(h))),
+        "variant_records_offset": int(lib.pgo_vw_variant_records_offset(C.byref(h))),
+    }
+
+
+def vw_validate(h: VwHeader, file_bytes: bytes):
+    """The reference's two walks (src/pgen.rs:140-258) -> (pos after block offsets, pos after header body, types seen, length bytes seen)."""
+    buf = np.frombuffer(file_bytes, dtype=np.uint8)
+    p1 = int(lib.pgo_vw_check_variant_block_offsets(C.byref(h), _vp(buf), buf.size, 12))
+    types = np.zeros(256, dtype=np.uint8)
+    lens = np.zeros(256, dtype=np.uint8)
+    p2 = int(lib.pgo_vw_check_main_header_body(C.byref(h), _vp(buf), buf.size, max(p1, 0), _vp(types), _vp(lens)))
+    return p1, p2, sorted(np.nonzero(types)[0].tolist()), sorted(np.nonzero(lens)[0].tolist())
+
+
+def vw_index(h: VwHeader, file_bytes: bytes):
+    """-> (rc, types u8[V], lens u32[V], offs u64[V]); not in the reference (parity unpinned)."""
+    buf = np.frombuffer(file_bytes, dtype=np.uint8)
+    v = int(h.variant_count)
+    types = np.zeros(max(v, 1), dtype=np.uint8)
+    lens = np.zeros(max(v, 1), dtype=np.uint32)
+    offs = np.zeros(max(v, 1), dtype=np.uint64)
+    rc = int(lib.pgo_vw_index(C.byref(h), _vp(buf), buf.size, _vp(types), _vp(lens), _vp(offs)))
+    return rc, types[:v], lens[:v], offs[:v]
+
+
+def decode_emit_at(base: np.ndarray, record_off, num_samples: int, kept_idx=None) -> np.ndarray:
+    """GT segments of the records at byte offsets ``record_off`` of ``base`` (dense 4K+1 pitch)."""
+    base = np.ascontiguousarray(base, dtype=np.uint8)
+    off = np.ascontiguousarray(np.asarray(record_off, dtype=np.uint64))
+    kept = _u32(kept_idx)
+    K = num_samples if kept is None else int(kept.size)
+    out = np.zeros(max(off.size * (4 * K + 1), 1), dtype=np.uint8)
+    rc = lib.pgo_decode_emit_at(_vp(base), _vp(off), off.size, num_samples, _vp(kept), K, _vp(out), 4 * K + 1)
+    if rc != 0:
+        raise IndexError(f"oracle decode_emit_at failed: {rc}")
+    return out[: off.size * (4 * K + 1)]

@@ -21,6 +21,9 @@ from .engine import (  # noqa: F401
     parse_header,
     record_offset,
     variant_record_size,
+    vw_parse_header,
+    vw_select_uncompressed,
+    vw_walk_index,
 )
 
 __all__ = [
@@ -30,6 +33,9 @@ __all__ = [
     "parse_header",
     "record_offset",
     "variant_record_size",
+    "vw_parse_header",
+    "vw_walk_index",
+    "vw_select_uncompressed",
     "KERNEL_AUTO",
     "KERNEL_ROWS",
     "KERNEL_FLAT",

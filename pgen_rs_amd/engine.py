@@ -43,6 +43,45 @@ def device_count() -> int:
     return n.value if rc == 0 else 0
 
 
+# ---- variable-width storage modes: header and offset-table walk (src/pgen.rs) ---------
+def vw_parse_header(header: bytes) -> "_capi.VwHeader":
+    """12 header bytes of a variable-width .pgen -> ``pgenhip_vw_header`` (src/pgen.rs:21-137); raises on its asserts."""
+    if len(header) < 12:
+        raise _capi.PgenHipError(_capi.ERR_IO, "vw_parse_header: short header")
+    h = _capi.VwHeader()
+    check(lib.pgenhip_vw_parse_header(bytes(header[:12]), C.byref(h)), "pgenhip_vw_parse_header")
+    return h
+
+
+def vw_walk_index(h: "_capi.VwHeader", index: bytes):
+    """File bytes [12, variant_records_offset) -> (record_type u8[V], record_len u32[V], record_off u64[V]) (src/pgen.rs:140-258)."""
+    v = int(h.variant_count)
+    types = np.zeros(max(v, 1), dtype=np.uint8)
+    lens = np.zeros(max(v, 1), dtype=np.uint32)
+    offs = np.zeros(max(v, 1), dtype=np.uint64)
+    buf = np.frombuffer(bytes(index), dtype=np.uint8)
+    check(lib.pgenhip_vw_walk_index(C.byref(h), buf.ctypes.data_as(C.c_void_p) if buf.size else None, buf.size,
+                                    types.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p)),
+          "pgenhip_vw_walk_index")
+    return types[:v], lens[:v], offs[:v]
+
+
+def vw_select_uncompressed(types: np.ndarray, lens: np.ndarray, offs: np.ndarray, record_size: int,
+                           variant_idx: Optional[Sequence[int]] = None) -> np.ndarray:
+    """Byte offsets of the selected variants' records, all of which must be plain 2-bit records (type 0, length R);
+    raises ``PgenHipError`` with status ``ERR_COMPRESSED_RECORD`` otherwise."""
+    types = np.ascontiguousarray(types, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    vidx = None if variant_idx is None else np.ascontiguousarray(np.asarray(variant_idx, dtype=np.uint32))
+    n = int(types.size if vidx is None else vidx.size)
+    sel = np.zeros(max(n, 1), dtype=np.uint64)
+    check(lib.pgenhip_vw_select_uncompressed(types.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
+                                             int(types.size), vidx.ctypes.data_as(C.c_void_p) if vidx is not None and vidx.size else None, n,
+                                             record_size, sel.ctypes.data_as(C.c_void_p)), "pgenhip_vw_select_uncompressed")
+    return sel[:n]
+
+
 def _ptr(t: Optional[torch.Tensor], byte_offset: int = 0) -> Optional[int]:
     if t is None:
         return None
@@ -176,6 +215,23 @@ class GtEngine:
             ),
             "pgenhip_decode_emit",
         )
+        return out
+
+    def decode_emit_at(self, base: torch.Tensor, record_off: torch.Tensor, n_variants: int, out: Optional[torch.Tensor] = None,
+                       out_stride: Optional[int] = None, kernel: int = KERNEL_AUTO) -> torch.Tensor:
+        """GT segments of records addressed by BYTE OFFSET into ``base`` (``record_off``: int64 CUDA tensor): the
+        uncompressed records of a variable-width .pgen staged to HBM as it lies on disk."""
+        if out_stride is None:
+            out_stride = self.gt_row_bytes
+        if out is None:
+            out = torch.empty(max(n_variants, 1) * out_stride, dtype=torch.uint8, device=self.torch_device)
+        for t, name in ((base, "base"), (record_off, "record_off"), (out, "out")):
+            self._check_dev(t, name)
+        if record_off.dtype != torch.int64 or record_off.numel() < n_variants:
+            raise ValueError("record_off must be an int64 tensor (u64 byte offsets) with >= n_variants entries")
+        if n_variants and out.numel() < (n_variants - 1) * out_stride + self.gt_row_bytes:
+            raise ValueError("out too small")
+        check(lib.pgenhip_decode_emit_at(self._ctx, _ptr(base), _ptr(record_off), n_variants, _ptr(out), out_stride, kernel), "pgenhip_decode_emit_at")
         return out
 
     def emit_lines(

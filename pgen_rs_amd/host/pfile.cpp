@@ -63,6 +63,12 @@ std::string trim(const std::string &s)
     return s.substr(b, e - b);
 }
 
+std::string hex2(uint8_t b)
+{
+    static const char *d = "0123456789abcdef";
+    return std::string(1, d[b >> 4]) + d[b & 15];
+}
+
 void pread_exact(int fd, void *dst, size_t bytes, uint64_t offset, const std::string &path)
 {
     uint8_t *p = static_cast<uint8_t *>(dst);
@@ -114,10 +120,36 @@ Pfile Pfile::from_prefix(const std::string &pfile_prefix)
     const std::string path = pf.pgen_path();
     int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw PfileError("open " + path + ": " + std::strerror(errno));  // :41
+    struct FdCloser {
+        int fd;
+        ~FdCloser() { close(fd); }
+    } closer{fd};
     uint8_t hdr[12];
     ssize_t got = pread(fd, hdr, sizeof hdr, 0);
-    close(fd);
     if (got != (ssize_t)sizeof hdr) throw PfileError("read " + path + ": failed to fill whole buffer");  // :45 read_exact
+    if (hdr[0] == 0x6C && hdr[1] == 0x1B && hdr[2] != 0x02) {
+        // not the fixed-width mode the reference's tool accepts (:53): the variable-width header walk of src/pgen.rs:21-258
+        pgenhip_vw_header vh;
+        int vrc = pgenhip_vw_parse_header(hdr, &vh);
+        if (vrc == PGENHIP_ERR_BAD_FLAGS)
+            throw PfileError(path + ": storage mode 0x" + hex2(hdr[2]) + ": unsupported header format byte (" + pgenhip_last_error_detail() + ")");  // src/pgen.rs:58, :64
+        check(vrc, "pgenhip_vw_parse_header");
+        std::vector<uint8_t> index((size_t)(vh.variant_records_offset - 12ull));
+        pread_exact(fd, index.data(), index.size(), 12, path);
+        auto types = std::make_shared<std::vector<uint8_t>>(vh.variant_count);
+        auto lens = std::make_shared<std::vector<uint32_t>>(vh.variant_count);
+        auto offs = std::make_shared<std::vector<uint64_t>>(vh.variant_count);
+        vrc = pgenhip_vw_walk_index(&vh, index.data(), index.size(), types->data(), lens->data(), offs->data());
+        if (vrc == PGENHIP_ERR_BAD_INDEX) throw PfileError(path + ": " + pgenhip_last_error_detail());  // src/pgen.rs:160-165 panic
+        check(vrc, "pgenhip_vw_walk_index");
+        pf.storage_mode = hdr[2];
+        pf.num_variants = vh.variant_count;
+        pf.num_samples = vh.sample_count;
+        pf.vw_record_type = types;
+        pf.vw_record_len = lens;
+        pf.vw_record_off = offs;
+        return pf;
+    }
     int rc = pgenhip_parse_header(hdr, &pf.num_variants, &pf.num_samples);
     if (rc == PGENHIP_ERR_BAD_MAGIC) throw PfileError(path + ": assertion failed: magic number is not [0x6C, 0x1B]");          // :47
     if (rc == PGENHIP_ERR_BAD_MODE) throw PfileError(path + ": assertion failed: storage_mode == 0x02 (only the fixed-width mode is supported)");  // :53
@@ -128,6 +160,12 @@ Pfile Pfile::from_prefix(const std::string &pfile_prefix)
 
 // :196-200
 uint32_t Pfile::variant_record_size() const { return pgenhip_variant_record_size(num_samples); }
+
+uint64_t Pfile::record_offset(uint64_t var_idx) const
+{
+    if (variable_width()) return (*vw_record_off)[(size_t)var_idx];
+    return pgenhip_record_offset(var_idx, variant_record_size());  // :165, widened before the multiply
+}
 
 // :202-220
 std::pair<std::string, std::string> Pfile::read_pvar_header() const
@@ -371,6 +409,13 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
         file_off[j + 1] = file_off[j] + plen + 4ull * K + 1ull;
         if (var_idx_rcds[j].first >= num_variants)
             throw PfileError("variant row " + std::to_string(var_idx_rcds[j].first) + " is past the " + std::to_string(num_variants) + " records of " + pgen_path());
+        if (variable_width()) {
+            // only records stored as plain 2-bit hard calls (type 0, length R) can take the path of :165-190; anything else is reported
+            const size_t vi = var_idx_rcds[j].first;
+            if ((*vw_record_type)[vi] != 0 || (*vw_record_len)[vi] != R)
+                throw PfileError(pgen_path() + ": variant row " + std::to_string(vi) + " is stored compressed (record type " +
+                                 std::to_string((*vw_record_type)[vi]) + ", " + std::to_string((*vw_record_len)[vi]) + " bytes); only uncompressed 2-bit records are supported");
+        }
     }
     st.variants = V;
     st.samples_kept = K;
@@ -532,8 +577,11 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                 // :165-170 once per run of consecutive variant indices instead of once per variant
                 for (size_t j = 0; j < nv;) {
                     size_t run = 1;
-                    while (j + run < nv && var_idx_rcds[b0 + j + run].first == var_idx_rcds[b0 + j].first + run) run++;
-                    pread_exact(pfd, h_rec + j * R, run * (size_t)R, pgenhip_record_offset(var_idx_rcds[b0 + j].first, R), pgen);
+                    // (variable-width files: consecutive plain records are adjacent on disk too when nothing compressed lies between them)
+                    while (j + run < nv && var_idx_rcds[b0 + j + run].first == var_idx_rcds[b0 + j].first + run &&
+                           record_offset(var_idx_rcds[b0 + j + run].first) == record_offset(var_idx_rcds[b0 + j].first) + run * (uint64_t)R)
+                        run++;
+                    pread_exact(pfd, h_rec + j * R, run * (size_t)R, record_offset(var_idx_rcds[b0 + j].first), pgen);
                     j += run;
                 }
                 // :157-161 joined once per variant: col '\t' col '\t' ... "GT"

@@ -5,6 +5,7 @@
 // exists in this image, hence C++.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -38,12 +39,23 @@ class Pfile {
     std::string pfile_prefix;  // src/pfile.rs:20-22
     uint32_t num_variants = 0;
     uint32_t num_samples = 0;
+    // Variable-width storage modes (the reference refuses them at src/pfile.rs:53 and only validates
+    // their tables in the dead `Pgen` type, src/pgen.rs): per-variant record type / length / file offset from the
+    // header walk (pgenhip_vw_walk_index).  Empty for a fixed-width (0x02) file.
+    uint8_t storage_mode = 0x02;
+    std::shared_ptr<const std::vector<uint8_t>> vw_record_type;
+    std::shared_ptr<const std::vector<uint32_t>> vw_record_len;
+    std::shared_ptr<const std::vector<uint64_t>> vw_record_off;
+    bool variable_width() const { return static_cast<bool>(vw_record_off); }
+    // file offset of variant var_idx's record: src/pfile.rs:165 (u64), or the walked table
+    uint64_t record_offset(uint64_t var_idx) const;
 
     std::string pgen_path() const { return pfile_prefix + ".pgen"; }  // :26-36
     std::string psam_path() const { return pfile_prefix + ".psam"; }
     std::string pvar_path() const { return pfile_prefix + ".pvar"; }
 
-    // :38-76 — opens PREFIX.pgen and checks magic / storage mode 0x02 / flag byte 0x40
+    // :38-76 — opens PREFIX.pgen and checks magic / storage mode 0x02 / flag byte 0x40; any other storage mode goes through
+    // the variable-width header walk (src/pgen.rs:21-258) and is accepted when its tables are sound
     static Pfile from_prefix(const std::string &pfile_prefix);
 
     // :196-200

@@ -7,6 +7,7 @@ import shutil
 import subprocess
 from pathlib import Path
 
+import numpy as np
 import pytest
 
 import pgen_oracle as oracle
@@ -107,3 +108,87 @@ def test_logical_shards_concatenate_to_the_single_shard_file(basic1, tmp_path, s
             "--block-mib", "4", "-o", str(out))
     assert p.returncode == 0, p.stderr
     assert out.read_bytes() == expected_vcf(basic1, var_pred=lambda r: r[b"ALT"] == b"G")
+
+
+# ---- the reference's own dataset shape: data/basic2 (200 000 variants x 300 samples) -------------------------------------
+@pytest.fixture(scope="module")
+def basic2(tmp_path_factory):
+    """basic2.psam is the reference's own file (data/basic2/basic2.psam: per0..per299); its .pvar and .pgen are missing from
+    the mount, so they are synthesised at the documented shape (data/random1/info.txt, basic2.log)."""
+    d = tmp_path_factory.mktemp("basic2")
+    shutil.copy(GOLDEN / "basic2" / "basic2.psam", d / "basic2.psam")
+    n, v = 300, 200_000
+    with open(d / "basic2.pvar", "wb") as f:
+        f.write(b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\n")
+        f.write(b"".join(b"1\t%d\tsnp%d\tA\tG\n" % (1000 + i, i) for i in range(v)))
+    recs = oracle.synth_records(n, v)
+    (d / "basic2.pgen").write_bytes(bytes([0x6C, 0x1B, 0x02]) + v.to_bytes(4, "little") + n.to_bytes(4, "little") + b"\x40" + recs.tobytes())
+    return d / "basic2"
+
+
+def test_basic2_reference_smoke_query_ten_by_ten(basic2, tmp_path):
+    # the commented-out smoke test of the reference (src/main.rs:51-90): snp0..snp9 x per0..per9 on data/basic2
+    out = tmp_path / "ten.vcf"
+    vq = " || ".join(f'ID == "snp{i}"' for i in range(10))
+    sq = " || ".join(f'IID == "per{i}"' for i in range(10))
+    p = run("filter", str(basic2), "--include-var", vq, "--include-sam", sq, "-o", str(out))
+    assert p.returncode == 0, p.stderr
+    snps = {b"snp%d" % i for i in range(10)}
+    pers = {b"per%d" % i for i in range(10)}
+    want = expected_vcf(basic2, var_pred=lambda r: r[b"ID"] in snps, sam_pred=lambda r: r[b"IID"] in pers)
+    got = out.read_bytes()
+    assert got == want
+    lines = got.split(b"\n")
+    assert lines[1].endswith(b"FORMAT\t" + b"\t".join(b"per%d" % i for i in range(10))) and len(lines) == 2 + 1 + 10 + 1
+
+
+def test_basic2_whole_file(basic2, tmp_path):
+    """All 200 000 variants x 300 samples (rows of 1 201 bytes behind ~20-byte prefixes): 245 MB of VCF, byte for byte."""
+    out = tmp_path / "all.vcf"
+    p = run("filter", str(basic2), "-o", str(out), "--block-mib", "64")
+    assert p.returncode == 0, p.stderr
+    want = expected_vcf(basic2)
+    got = out.read_bytes()
+    assert len(got) == len(want) and hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
+
+
+# ---- a variable-width (mode 0x10) file through the CLI (SURVEY.md §8f N4) ---------------------------------------------
+@pytest.fixture(scope="module")
+def vw_pfile(tmp_path_factory):
+    import sys
+
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden_vw as writer
+
+    d = tmp_path_factory.mktemp("vw")
+    n, v = 2504, 3000
+    rng = np.random.default_rng(2026)
+    types = np.where(rng.random(v) < 0.8, 0, rng.integers(1, 8, size=v)).tolist()
+    types[0] = 0
+    recs = writer.make_records(rng, n, types)
+    data, _ = writer.write_vw(n, recs, 8, 2)
+    (d / "vw.pgen").write_bytes(data)
+    with open(d / "vw.pvar", "wb") as f:
+        f.write(b"#CHROM\tPOS\tID\tREF\tALT\tRTYPE\n")
+        f.write(b"".join(b"7\t%d\tv%d\tC\tT\t%d\n" % (500 + 3 * i, i, t) for i, t in enumerate(types)))
+    with open(d / "vw.psam", "wb") as f:
+        f.write(b"#IID\tSEX\n" + b"".join(b"S%04d\tNA\n" % i for i in range(n)))
+    return d / "vw"
+
+
+def test_variable_width_file_plain_records(vw_pfile, tmp_path):
+    out = tmp_path / "plain.vcf"
+    p = run("filter", str(vw_pfile), "--include-var", 'RTYPE == "0"', "--block-mib", "2", "-o", str(out))
+    assert p.returncode == 0, p.stderr
+    assert out.read_bytes() == expected_vcf(vw_pfile, var_pred=lambda r: r[b"RTYPE"] == b"0")
+    out2 = tmp_path / "plain_sub.vcf"
+    p = run("filter", str(vw_pfile), "--include-var", 'RTYPE == "0" && REF == "C"', "--include-sam", 'IID != "S0007"', "-o", str(out2))
+    assert p.returncode == 0, p.stderr
+    assert out2.read_bytes() == expected_vcf(vw_pfile, var_pred=lambda r: r[b"RTYPE"] == b"0", sam_pred=lambda r: r[b"IID"] != b"S0007")
+
+
+def test_variable_width_file_compressed_record_exits_101(vw_pfile, tmp_path):
+    p = run("filter", str(vw_pfile), "-o", str(tmp_path / "x.vcf"))   # every variant, the compressed ones too
+    assert p.returncode == 101 and b"stored compressed" in p.stderr
+    q = run("query", str(vw_pfile), "-i", 'RTYPE != "0"', "-f", "ID")     # metadata queries never touch the records
+    assert q.returncode == 0 and q.stdout.startswith(b"v")
