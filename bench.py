@@ -54,6 +54,12 @@ CONFIGS = {
 }
 
 
+DISTRIBUTIONS = {
+    "uniform": "uniform 2-bit codes (splitmix64 counter generator, SURVEY.md §8d)",
+    "hwe": "hwe: per-variant allele frequency in [0.01, 0.5), Hardy-Weinberg genotype proportions, 0.1 % missing (PGENHIP_SYNTH_HWE, SURVEY.md §8d)",
+}
+
+
 def cpu_baseline(n_samples: int, kept, target_s: float = 12.0) -> dict:
     """Times the oracle's file-to-file literal restatement of src/pfile.rs:149-192 on one core.
 
@@ -136,7 +142,7 @@ def cpu_baseline(n_samples: int, kept, target_s: float = 12.0) -> dict:
     }
 
 
-def host_delivered(torch, pgen_rs_amd, dev_index: int, n: int, kept, v_avail: int, target_out_bytes: float = 12e9) -> dict:
+def host_delivered(torch, pgen_rs_amd, dev_index: int, n: int, kept, v_avail: int, target_out_bytes: float = 12e9, hwe: bool = False) -> dict:
     """PCIe-inclusive rate of the same path (src/pfile.rs:149-190 without the file system): records start in
     pinned host memory, blocks go H2D -> pgenhip_decode_emit -> D2H into a pinned host ring on two streams
     with one ctx each (what host/pfile.cpp does around its pread/pwrite).  Run OUTSIDE the timed region."""
@@ -150,7 +156,7 @@ def host_delivered(torch, pgen_rs_amd, dev_index: int, n: int, kept, v_avail: in
         v = min(v, v_avail)
         n_blocks = (v + block - 1) // block
         h_recs = torch.empty(v * r, dtype=torch.uint8).pin_memory()
-        h_recs.copy_(e0.synth_records(v, seed=SEED_DATA)[: v * r].cpu())
+        h_recs.copy_(e0.synth_records(v, seed=SEED_DATA, hwe=hwe)[: v * r].cpu())
         ring = 4
         h_out = [torch.empty(block * row, dtype=torch.uint8).pin_memory() for _ in range(ring)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
@@ -258,6 +264,9 @@ def main() -> int:
     ap.add_argument("--variants", type=int, default=None, help="custom TOTAL variants (overrides the config's)")
     ap.add_argument("--samples", type=int, default=None, help="custom sample count (overrides the config's)")
     ap.add_argument("--keep-modulus", type=int, default=None, help="keep sample i iff splitmix64(seed^i) %% m == 0 (0 = all)")
+    ap.add_argument("--distribution", choices=["uniform", "hwe"], default="uniform",
+                    help="value distribution of the synthetic records (SURVEY.md §8d): uniform 2-bit codes, or per-variant allele "
+                         "frequencies with Hardy-Weinberg genotype proportions and 0.1 %% missing (mostly 0/0, like real data)")
     ap.add_argument("--max-launch-variants", type=int, default=0, help="cap on variants per launch (0 = as many as fit in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-delivered", action="store_true")
@@ -315,8 +324,16 @@ def main() -> int:
     begin, end = shard_range(v_total, world, rank)  # this rank's contiguous slice of the kept-variant list
     v = end - begin
 
+    # PCIe-inclusive rate first, on its own small buffers (measured outside the timed region; done before the big
+    # allocations so that it does not run beside the driver unmapping 200 GB of freed output buffer)
+    hd = None
+    if world == 1 and rank == 0 and not args.no_host_delivered and v > 0:
+        hd = host_delivered(torch, pgen_rs_amd, local_rank, n, kept, v, hwe=args.distribution == "hwe")
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()
+
     # the rank's records, resident before the timed region; then as many output rows as fit beside them
-    recs = eng.synth_records(v, first_variant=begin, seed=SEED_DATA)
+    recs = eng.synth_records(v, first_variant=begin, seed=SEED_DATA, hwe=args.distribution == "hwe")
     torch.cuda.synchronize(dev)
     free_b, _total_b = torch.cuda.mem_get_info(dev)
     share = world if args.all_ranks_on_device0 else 1
@@ -405,7 +422,7 @@ def main() -> int:
                 "samples": n,
                 "kept_samples": k,
                 "sharding": f"contiguous variant ranges, {world} rank(s), no collective",
-                "distribution": "uniform 2-bit codes (splitmix64 counter generator, SURVEY.md §8d)",
+                "distribution": DISTRIBUTIONS[args.distribution],
             },
             "vcf_MB_per_s": v_total * (4 * k + 1) * args.steps / dt_max / 1e6,
             "genotypes_emitted_per_s": v_total * k * args.steps / dt_max,
@@ -429,10 +446,8 @@ def main() -> int:
             },
             "self_check": check,
         }
-        del out
-        torch.cuda.empty_cache()
-        if world == 1 and not args.no_host_delivered:
-            line["host_delivered"] = host_delivered(torch, pgen_rs_amd, local_rank, n, kept, v)
+        if hd is not None:
+            line["host_delivered"] = hd
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, kept)
         print(json.dumps(line), flush=True)

@@ -230,6 +230,11 @@ int pgenhip_memcpy_d2h(pgenhip_ctx *ctx, void *h_dst, const void *d_src, size_t 
 
 /* ---- synthetic records generated on the device --------- */
 #define PGENHIP_SYNTH_DIRTY_PAD 1u
+/* "hwe" value distribution instead of uniform codes: variant v has allele frequency
+ * p = (655 + splitmix64((seed ^ 0x4D4146) + v) % 32113) / 65536 in [0.01, 0.5); sample s draws two alleles from
+ * h = splitmix64(splitmix64((seed ^ 0x485745) + v) + s) (low two 16-bit fields < p * 65536) -> codes 0/1/2 in
+ * Hardy-Weinberg proportions, and is missing (code 3) when h >> 32 < 4294967 (0.1 %).  Pad bits zero. */
+#define PGENHIP_SYNTH_HWE 2u
 /* record bytes of variant v = LE words splitmix64(seed + (v << 20) + word_idx), truncated to R;
  * pad bits of the last byte zeroed unless PGENHIP_SYNTH_DIRTY_PAD (the tests hold a CPU twin). */
 int pgenhip_synth_records(pgenhip_ctx *ctx, void *d_dst, uint64_t record_stride,

@@ -252,6 +252,36 @@ void pgo_synth_records(uint8_t *dst, uint64_t record_stride, uint32_t num_sample
     }
 }
 
+/* SURVEY.md §8d "hwe" value distribution (not from the reference: pgen-rs has no generator; real genotype data is
+ * mostly 0/0, and write bandwidth on MI355X is data dependent, so the bench needs it).  Integer-only so that the
+ * device twin is bit-exact:
+ *   variant v:  p16 = 655 + splitmix64((seed ^ "MAF") + v) % 32113          allele frequency p = p16 / 65536 in [0.01, 0.5)
+ *               kv  = splitmix64((seed ^ "HWE") + v)
+ *   sample s:   h = splitmix64(kv + s);  two independent allele draws a = (h & 0xFFFF) < p16, b = ((h >> 16) & 0xFFFF) < p16
+ *               code = a + b  (0 = 0/0, 1 = 0/1, 2 = 1/1: Hardy-Weinberg proportions q^2, 2pq, p^2)
+ *               missing (code 3) when the top 32 bits of h are < 4294967 (0.1 %).
+ * Pad bits of the last byte are zero. */
+#define PGO_SEED_MAF 0x4D4146ull
+#define PGO_SEED_HWE 0x485745ull
+void pgo_synth_records_hwe(uint8_t *dst, uint64_t record_stride, uint32_t num_samples,
+                           uint64_t first_variant, uint32_t n_variants, uint64_t seed)
+{
+    uint32_t R = pgo_variant_record_size(num_samples);
+    for (uint32_t j = 0; j < n_variants; j++) {
+        uint64_t v = first_variant + j;
+        uint8_t *rec = dst + (uint64_t)j * record_stride;
+        uint32_t p16 = 655u + (uint32_t)(pgo_splitmix64((seed ^ PGO_SEED_MAF) + v) % 32113ull);
+        uint64_t kv = pgo_splitmix64((seed ^ PGO_SEED_HWE) + v);
+        for (uint32_t b = 0; b < R; b++) rec[b] = 0;
+        for (uint32_t s = 0; s < num_samples; s++) {
+            uint64_t h = pgo_splitmix64(kv + (uint64_t)s);
+            uint32_t code = (uint32_t)((h & 0xFFFFu) < p16) + (uint32_t)(((h >> 16) & 0xFFFFu) < p16);
+            if ((uint32_t)(h >> 32) < 4294967u) code = 3u;
+            rec[s >> 2] |= (uint8_t)(code << ((s & 3u) * 2u));
+        }
+    }
+}
+
 uint32_t pgo_synth_keep(uint32_t num_samples, uint64_t seed, uint32_t modulus,
                         uint32_t *kept_idx, uint32_t cap)
 {

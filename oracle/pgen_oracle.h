@@ -87,6 +87,10 @@ uint64_t pgo_splitmix64(uint64_t x);
 void pgo_synth_records(uint8_t *dst, uint64_t record_stride, uint32_t num_samples,
                        uint64_t first_variant, uint32_t n_variants,
                        uint64_t seed, int dirty_pad);
+/* "hwe" value distribution: per-variant allele frequency in [0.01, 0.5), codes 0/1/2 in Hardy-Weinberg
+ * proportions, 0.1 % missing; integer-only, see pgen_oracle.c.  Twin of PGENHIP_SYNTH_HWE. */
+void pgo_synth_records_hwe(uint8_t *dst, uint64_t record_stride, uint32_t num_samples,
+                           uint64_t first_variant, uint32_t n_variants, uint64_t seed);
 /* keep sample i iff splitmix64(seed ^ i) % modulus == 0; writes ascending
  * indices to kept_idx (capacity cap) and returns the kept count. */
 uint32_t pgo_synth_keep(uint32_t num_samples, uint64_t seed, uint32_t modulus,

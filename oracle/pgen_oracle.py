@@ -40,6 +40,8 @@ def _load() -> C.CDLL:
     h.pgo_splitmix64.argtypes = [C.c_uint64]
     h.pgo_synth_records.restype = None
     h.pgo_synth_records.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int]
+    h.pgo_synth_records_hwe.restype = None
+    h.pgo_synth_records_hwe.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64]
     h.pgo_synth_keep.restype = C.c_uint32
     h.pgo_synth_keep.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_uint32]
     # variable-width header walk (pgen_vw_oracle.c)
@@ -157,12 +159,15 @@ def splitmix64(x: int) -> int:
 
 
 def synth_records(num_samples: int, n_variants: int, first_variant: int = 0, seed: int = 0x5047454E,
-                  record_stride: Optional[int] = None, dirty_pad: bool = False) -> np.ndarray:
+                  record_stride: Optional[int] = None, dirty_pad: bool = False, hwe: bool = False) -> np.ndarray:
     R = variant_record_size(num_samples)
     if record_stride is None:
         record_stride = R
     dst = np.zeros(max(n_variants * record_stride, 1), dtype=np.uint8)
-    lib.pgo_synth_records(_vp(dst), record_stride, num_samples, first_variant, n_variants, seed, int(dirty_pad))
+    if hwe:
+        lib.pgo_synth_records_hwe(_vp(dst), record_stride, num_samples, first_variant, n_variants, seed)
+    else:
+        lib.pgo_synth_records(_vp(dst), record_stride, num_samples, first_variant, n_variants, seed, int(dirty_pad))
     return dst[: n_variants * record_stride]
 
 

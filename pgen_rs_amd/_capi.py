@@ -40,6 +40,7 @@ KERNEL_WIDE = 4
 KERNEL_PICK = 6
 KERNEL_RUNS = 7
 SYNTH_DIRTY_PAD = 1
+SYNTH_HWE = 2
 CREATE_KEEP_LIST = 1
 LAUNCHES_IN_FLIGHT = 16
 

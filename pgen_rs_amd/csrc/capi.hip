@@ -683,6 +683,12 @@ int pgenhip_synth_records(pgenhip_ctx *ctx, void *d_dst, uint64_t record_stride,
     if (rc) return rc;
     if (n_variants && ctx->record_size && !d_dst) return fail(PGENHIP_ERR_BAD_ARG, "d_dst is NULL");
     if (n_variants > 1 && record_stride < ctx->record_size) return fail(PGENHIP_ERR_BAD_ARG, "record_stride < record size");
+    if (flags & ~(PGENHIP_SYNTH_DIRTY_PAD | PGENHIP_SYNTH_HWE)) return fail(PGENHIP_ERR_BAD_ARG, "unknown synth flag");
+    if (flags & PGENHIP_SYNTH_HWE) {
+        HIP_TRY(launch_synth_records_hwe(static_cast<uint8_t *>(d_dst), record_stride, ctx->sample_count, first_variant, n_variants, seed,
+                                         ctx->num_cus, ctx->stream));
+        return PGENHIP_OK;
+    }
     HIP_TRY(launch_synth_records(static_cast<uint8_t *>(d_dst), record_stride, ctx->sample_count, first_variant,
                                  n_variants, seed, (flags & PGENHIP_SYNTH_DIRTY_PAD) != 0, ctx->num_cus, ctx->stream));
     return PGENHIP_OK;

@@ -181,7 +181,54 @@ __global__ __launch_bounds__(256) void synth_records_kernel(uint8_t *dst, uint64
         }
     }
 }
+
+// "hwe" distribution: per-variant allele frequency p16 / 65536 in [0.01, 0.5), two independent allele
+// draws per sample (codes 0/1/2 in Hardy-Weinberg proportions), 0.1 % missing; integer-only — the oracle holds the twin.
+// One thread per 64-bit word of a record (32 samples).
+__global__ __launch_bounds__(256) void synth_records_hwe_kernel(uint8_t *dst, uint64_t record_stride, uint32_t sample_count,
+                                                                uint32_t record_size, uint64_t first_variant, uint32_t n_variants, uint64_t seed)
+{
+    const uint32_t words_per_rec = (record_size + 7u) / 8u;
+    const uint64_t total = (uint64_t)n_variants * words_per_rec;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += step) {
+        const uint32_t j = (uint32_t)(idx / words_per_rec);
+        const uint32_t w = (uint32_t)(idx - (uint64_t)j * words_per_rec);
+        const uint64_t v = first_variant + j;
+        const uint32_t p16 = 655u + (uint32_t)(splitmix64((seed ^ 0x4D4146ull) + v) % 32113ull);
+        const uint64_t kv = splitmix64((seed ^ 0x485745ull) + v);
+        uint64_t val = 0ull;
+        const uint32_t s0 = w * 32u;
+        for (uint32_t i = 0; i < 32u && s0 + i < sample_count; i++) {
+            const uint64_t h = splitmix64(kv + (uint64_t)(s0 + i));
+            uint32_t code = (uint32_t)((uint32_t)(h & 0xFFFFull) < p16) + (uint32_t)((uint32_t)((h >> 16) & 0xFFFFull) < p16);
+            if ((uint32_t)(h >> 32) < 4294967u) code = 3u;
+            val |= (uint64_t)code << (2u * i);
+        }
+        const uint32_t byte0 = w * 8u;
+        const uint32_t nbytes = min(8u, record_size - byte0);
+        uint8_t *p = dst + (uint64_t)j * record_stride + byte0;
+        if (nbytes == 8u && (((uintptr_t)p) & 7u) == 0u) {
+            *reinterpret_cast<uint64_t *>(p) = val;
+        } else {
+            for (uint32_t b = 0; b < nbytes; b++) p[b] = (uint8_t)(val >> (8u * b));
+        }
+    }
+}
 }  // namespace
+
+hipError_t launch_synth_records_hwe(uint8_t *dst, uint64_t record_stride, uint32_t sample_count, uint64_t first_variant,
+                                    uint32_t n_variants, uint64_t seed, int num_cus, hipStream_t stream)
+{
+    const uint32_t record_size = (sample_count * 2u) / 8u + (((sample_count * 2u) % 8u) ? 1u : 0u);
+    if (n_variants == 0 || record_size == 0) return hipSuccess;
+    const uint64_t total = (uint64_t)n_variants * ((record_size + 7u) / 8u);
+    const uint64_t blocks_needed = (total + 255ull) / 256ull;
+    const uint64_t max_grid = (uint64_t)num_cus * 16ull;
+    hipLaunchKernelGGL(synth_records_hwe_kernel, dim3((uint32_t)(blocks_needed < max_grid ? blocks_needed : max_grid)), dim3(256), 0, stream,
+                       dst, record_stride, sample_count, record_size, first_variant, n_variants, seed);
+    return hipGetLastError();
+}
 
 hipError_t launch_synth_records(uint8_t *dst, uint64_t record_stride, uint32_t sample_count,
                                 uint64_t first_variant, uint32_t n_variants, uint64_t seed,

@@ -80,4 +80,8 @@ hipError_t launch_synth_records(uint8_t *dst, uint64_t record_stride, uint32_t s
                                 uint64_t first_variant, uint32_t n_variants, uint64_t seed,
                                 bool dirty_pad, int num_cus, hipStream_t stream);
 
+// "hwe" value distribution (per-variant allele frequency, Hardy-Weinberg genotype proportions, 0.1 % missing)
+hipError_t launch_synth_records_hwe(uint8_t *dst, uint64_t record_stride, uint32_t sample_count, uint64_t first_variant,
+                                    uint32_t n_variants, uint64_t seed, int num_cus, hipStream_t stream);
+
 }  // namespace pgenhip

@@ -284,8 +284,10 @@ class GtEngine:
         dirty_pad: bool = False,
         out: Optional[torch.Tensor] = None,
         out_offset: int = 0,
+        hwe: bool = False,
     ) -> torch.Tensor:
-        """Synthetic records generated on the device (bit-exact twin of the oracle's generator)."""
+        """Synthetic records generated on the device (bit-exact twin of the oracle's generator); ``hwe``: the
+        Hardy-Weinberg value distribution of SURVEY.md §8d instead of uniform codes."""
         if record_stride is None:
             record_stride = self.record_size
         if out is None:
@@ -294,7 +296,7 @@ class GtEngine:
         check(
             lib.pgenhip_synth_records(
                 self._ctx, _ptr(out, out_offset), record_stride, first_variant, n_variants, seed,
-                _capi.SYNTH_DIRTY_PAD if dirty_pad else 0,
+                (_capi.SYNTH_DIRTY_PAD if dirty_pad else 0) | (_capi.SYNTH_HWE if hwe else 0),
             ),
             "pgenhip_synth_records",
         )

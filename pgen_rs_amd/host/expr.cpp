@@ -1,6 +1,7 @@
 // expr.cpp — see expr.h for the restated `evalexpr` semantics.
 #include "expr.h"
 
+#include <cerrno>
 #include <cmath>
 #include <cstdlib>
 
@@ -73,7 +74,10 @@ std::vector<Token> tokenize(const std::string &src)
                 tk.f = std::strtod(num.c_str(), nullptr);
             } else {
                 tk.t = Tok::INT;
+                errno = 0;
                 tk.i = std::strtoll(num.c_str(), nullptr, 10);
+                // evalexpr parses integer literals into i64 and reports what does not fit; never saturate silently
+                if (errno == ERANGE) throw ExprError("expression \"" + src + "\": integer literal " + num + " does not fit 64 bits");
             }
             p = q;
         } else if ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '_') {
@@ -232,7 +236,10 @@ Value eval_node(const Expr::Node *n, const std::vector<std::string> &row, const 
                 if (v.kind != Value::BOOL) throw bad("expected a boolean for '!', got " + v.describe());
                 return Value::boolean(!v.b);
             }
-            if (v.kind == Value::INT) return Value::integer(-v.i);
+            if (v.kind == Value::INT) {
+                if (v.i == INT64_MIN) throw bad("integer overflow in unary '-'");  // evalexpr: checked arithmetic
+                return Value::integer(-v.i);
+            }
             if (v.kind == Value::FLOAT) return Value::floating(-v.f);
             throw bad("expected a number for unary '-', got " + v.describe());
         }
@@ -273,11 +280,19 @@ Value eval_node(const Expr::Node *n, const std::vector<std::string> &row, const 
             if (n->op == Tok::HAT) return Value::floating(std::pow(as_f(a), as_f(b)));
             if (a.kind == Value::INT && b.kind == Value::INT) {
                 switch (n->op) {
-                    case Tok::PLUS: return Value::integer(a.i + b.i);
-                    case Tok::MINUS: return Value::integer(a.i - b.i);
-                    case Tok::STAR: return Value::integer(a.i * b.i);
-                    case Tok::SLASH: if (b.i == 0) throw bad("division by zero"); return Value::integer(a.i / b.i);
-                    default: if (b.i == 0) throw bad("modulo by zero"); return Value::integer(a.i % b.i);
+                    // evalexpr's integer operators are checked (an overflow is an error, i.e. a panic / exit 101 in pgen-rs, not
+                    // a wrapped or saturated value); C++ signed overflow would be undefined behaviour, INT64_MIN / -1 a trap
+                    case Tok::PLUS: { int64_t r; if (__builtin_add_overflow(a.i, b.i, &r)) throw bad("integer overflow in '+'"); return Value::integer(r); }
+                    case Tok::MINUS: { int64_t r; if (__builtin_sub_overflow(a.i, b.i, &r)) throw bad("integer overflow in '-'"); return Value::integer(r); }
+                    case Tok::STAR: { int64_t r; if (__builtin_mul_overflow(a.i, b.i, &r)) throw bad("integer overflow in '*'"); return Value::integer(r); }
+                    case Tok::SLASH:
+                        if (b.i == 0) throw bad("division by zero");
+                        if (a.i == INT64_MIN && b.i == -1) throw bad("integer overflow in '/'");
+                        return Value::integer(a.i / b.i);
+                    default:
+                        if (b.i == 0) throw bad("modulo by zero");
+                        if (a.i == INT64_MIN && b.i == -1) throw bad("integer overflow in '%'");
+                        return Value::integer(a.i % b.i);
                 }
             }
             const double x = as_f(a), y = as_f(b);

@@ -79,6 +79,24 @@ def synth_numpy(n_samples: int, first_variant: int, n_variants: int, seed: int, 
     return rec
 
 
+def synth_hwe_numpy(n_samples: int, first_variant: int, n_variants: int, seed: int) -> np.ndarray:
+    """(V, R) uint8 of the "hwe" value distribution (definition in include/pgen_hip.h, PGENHIP_SYNTH_HWE)."""
+    r = record_size(n_samples)
+    with np.errstate(over="ignore"):
+        v = np.arange(first_variant, first_variant + n_variants, dtype=np.uint64)
+        p16 = (np.uint64(655) + splitmix64_np(((np.uint64(seed) ^ np.uint64(0x4D4146)) + v) & MASK64) % np.uint64(32113)).astype(np.uint64)
+        kv = splitmix64_np(((np.uint64(seed) ^ np.uint64(0x485745)) + v) & MASK64)
+        h = splitmix64_np((kv[:, None] + np.arange(n_samples, dtype=np.uint64)[None, :]) & MASK64)
+    a = (h & np.uint64(0xFFFF)) < p16[:, None]
+    b = ((h >> np.uint64(16)) & np.uint64(0xFFFF)) < p16[:, None]
+    code = a.astype(np.uint8) + b.astype(np.uint8)
+    code[(h >> np.uint64(32)) < np.uint64(4294967)] = 3
+    padded = np.zeros((n_variants, 4 * r), dtype=np.uint8)
+    padded[:, :n_samples] = code
+    q = padded.reshape(n_variants, r, 4)
+    return (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8)
+
+
 def keep_numpy(n_samples: int, seed: int, modulus: int) -> np.ndarray:
     i = np.arange(n_samples, dtype=np.uint64)
     h = splitmix64_np(np.uint64(seed) ^ i)
@@ -132,8 +150,15 @@ def sha_cases() -> None:
         ("synth_n500000_v2", 500000, 34358, 2, 0x5047454E, None, False),
         ("synth_n500000_v2_keep100", 500000, 34358, 2, 0x5047454E, (0x4D41534B, 100), False),
     ]
-    for name, n, first, v, seed, keep, dirty in specs:
-        recs = synth_numpy(n, first, v, seed, dirty)
+    hwe_specs = [
+        ("hwe_n2504_v64", 2504, 0, 64, 0x5047454E, None, False),
+        ("hwe_n301_v50_from777", 301, 777, 50, 0x5047454E, None, False),
+        ("hwe_n50001_v8_keep100", 50001, 99_999, 8, 0x5047454E, (0x4D41534B, 100), False),
+        ("hwe_n500000_v2", 500000, 34359, 2, 0x5047454E, None, False),
+    ]
+    for name, n, first, v, seed, keep, dirty in specs + hwe_specs:
+        hwe = name.startswith("hwe_")
+        recs = synth_hwe_numpy(n, first, v, seed) if hwe else synth_numpy(n, first, v, seed, dirty)
         kept = keep_numpy(n, *keep) if keep else None
         gt = decode_numpy(recs, n, kept)
         table[name] = {
@@ -144,6 +169,7 @@ def sha_cases() -> None:
             "keep_seed": keep[0] if keep else None,
             "keep_modulus": keep[1] if keep else None,
             "dirty_pad": dirty,
+            "distribution": "hwe" if hwe else "uniform",
             "kept_count": int(kept.size) if kept is not None else n,
             "records_sha256": hashlib.sha256(recs.tobytes()).hexdigest(),
             "gt_sha256": hashlib.sha256(gt.tobytes()).hexdigest(),

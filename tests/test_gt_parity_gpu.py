@@ -80,10 +80,14 @@ def test_golden_sha_with_device_synth(name):
     n, v = spec["sample_count"], spec["n_variants"]
     kept = oracle.synth_keep(n, spec["keep_seed"], spec["keep_modulus"]) if spec["keep_modulus"] else None
     with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
-        recs = eng.synth_records(v, first_variant=spec["first_variant"], seed=spec["seed"], dirty_pad=spec["dirty_pad"])
+        recs = eng.synth_records(v, first_variant=spec["first_variant"], seed=spec["seed"], dirty_pad=spec["dirty_pad"],
+                                 hwe=spec["distribution"] == "hwe")
         eng.wait()
         assert hashlib.sha256(recs.cpu().numpy().tobytes()).hexdigest() == spec["records_sha256"]
-        for kern in kernels_for(kept is not None, True, n):
+        ks = kernels_for(kept is not None, True, n)
+        if kept is None and 8 <= n <= 1915:
+            ks.append(_capi.KERNEL_RUNS)
+        for kern in ks:
             out = eng.decode_emit(recs, v, kernel=kern)
             eng.wait()
             assert out.numel() == spec["gt_bytes"]
@@ -539,14 +543,16 @@ def test_emit_lines_tiny_keep_lists(n, k):
             assert (got[v * (4 * k + 1) :] == SENTINEL).all()
 
 
-def test_device_synth_matches_oracle_twin():
-    for n, v, first, stride_pad, dirty in [(2504, 33, 0, 0, False), (10007, 9, 123, 3, True), (5, 4, 2**31, 0, False), (500000, 2, 999_999, 0, False)]:
+@pytest.mark.parametrize("hwe", [False, True])
+def test_device_synth_matches_oracle_twin(hwe):
+    for n, v, first, stride_pad, dirty in [(2504, 33, 0, 0, False), (10007, 9, 123, 3, not hwe), (5, 4, 2**31, 0, False), (500000, 2, 999_999, 0, False),
+                                           (301, 700, 5, 1, False)]:
         r = oracle.variant_record_size(n)
         with pgen_rs_amd.GtEngine(n, device=0) as eng:
-            t = eng.synth_records(v, first_variant=first, record_stride=r + stride_pad, dirty_pad=dirty)
+            t = eng.synth_records(v, first_variant=first, record_stride=r + stride_pad, dirty_pad=dirty, hwe=hwe)
             eng.wait()
             got = t.cpu().numpy()
-        want = oracle.synth_records(n, v, first, record_stride=r + stride_pad, dirty_pad=dirty)
+        want = oracle.synth_records(n, v, first, record_stride=r + stride_pad, dirty_pad=dirty, hwe=hwe)
         got2 = got[: want.size].reshape(v, r + stride_pad)[:, :r]
         assert (got2 == want.reshape(v, r + stride_pad)[:, :r]).all()
 

@@ -119,6 +119,15 @@ def test_expression_subset(tmp_path, expr, want):
     ["-f", 'POS == "10"'],                  # fstring not a string
     ["-i", 'POS == 10 && "x"', "-f", "ID"],  # && on a non-boolean
     ["-f", "len(ID)"],                      # functions are outside the restated subset
+    # checked integer arithmetic (evalexpr reports overflow; the restatement must not wrap, saturate or trap): ADVICE r1
+    ["-i", "9223372036854775807 + 1 == 0", "-f", "ID"],
+    ["-i", "0 - 9223372036854775807 - 2 == 0", "-f", "ID"],
+    ["-i", "3037000500 * 3037000500 == 0", "-f", "ID"],
+    ["-i", "(0 - 9223372036854775807 - 1) / (0 - 1) == 0", "-f", "ID"],
+    ["-i", "(0 - 9223372036854775807 - 1) % (0 - 1) == 0", "-f", "ID"],
+    ["-i", "-(0 - 9223372036854775807 - 1) == 0", "-f", "ID"],
+    ["-i", "99999999999999999999 == 0", "-f", "ID"],
+    ["-i", "1 / 0 == 0", "-f", "ID"],
 ])
 def test_expression_errors_exit_101(tmp_path, args):
     pre = write_meta(tmp_path, b"#CHROM\tPOS\tID\n1\t10\tr1\n", PSAM)

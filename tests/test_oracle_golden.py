@@ -28,7 +28,7 @@ def test_oracle_matches_golden_case(name):
 def test_oracle_matches_golden_sha(name):
     spec = sha_table()[name]
     n, v = spec["sample_count"], spec["n_variants"]
-    recs = oracle.synth_records(n, v, spec["first_variant"], spec["seed"], dirty_pad=spec["dirty_pad"])
+    recs = oracle.synth_records(n, v, spec["first_variant"], spec["seed"], dirty_pad=spec["dirty_pad"], hwe=spec["distribution"] == "hwe")
     assert hashlib.sha256(recs.tobytes()).hexdigest() == spec["records_sha256"]  # C generator == numpy generator
     kept = None
     if spec["keep_modulus"]:
@@ -121,3 +121,22 @@ def test_emit_lines_oracle():
     got = oracle.emit_lines(recs, v, n, blob, poff, loff)
     seg = oracle.decode_emit(recs, v, n).reshape(v, -1)
     assert got.tobytes() == b"".join(p + s.tobytes() for p, s in zip(prefixes, seg))
+
+
+def test_hwe_distribution_is_what_it_says():
+    """SURVEY.md §8d "hwe": per-variant allele frequency p in [0.01, 0.5), genotype codes in Hardy-Weinberg proportions
+    (q^2, 2pq, p^2) and 0.1 % missing.  Checked on the oracle's generator (the device twin is compared byte for byte in the
+    GPU leg): every variant's observed allele frequency matches its p16, heterozygosity matches 2pq, missing rate 0.1 %."""
+    n, v = 200_000, 6
+    recs = oracle.synth_records(n, v, first_variant=1234, hwe=True).reshape(v, -1)
+    codes = ((recs[:, :, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)) & 3).reshape(v, -1)[:, :n]
+    for j in range(v):
+        p = (655 + oracle.splitmix64((0x5047454E ^ 0x4D4146) + 1234 + j) % 32113) / 65536.0
+        assert 0.0099 < p < 0.5
+        c = codes[j]
+        called = c[c != 3]
+        assert abs((c == 3).mean() - 0.001) < 0.0004
+        af = (called == 1).mean() * 0.5 + (called == 2).mean()
+        assert abs(af - p) < 0.004
+        assert abs((called == 1).mean() - 2 * p * (1 - p)) < 0.006
+    assert (recs[:, -1] >> ((n % 4) * 2 if n % 4 else 8) == 0).all()

@@ -1,16 +1,18 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): plain bench line, rocprofv3 kernel-trace stats, and the two
-# PMC passes (FETCH_SIZE / WRITE_SIZE need separate runs: TCC has 4 counter slots).
+# PMC passes (FETCH_SIZE / WRITE_SIZE need separate runs: TCC has 4 counter slots); then the
+# summary files that get committed under profiles/<tag>/ (tools/summarize_profile.py).
 # usage: tools/profile_bench.sh <tag> [bench args...]
 set -o pipefail
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $OUT/pmc_fetch.log; exit 1; }
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -5 $OUT/pmc_write.log; exit 1; }
-cat $OUT/bench.json
-find $OUT -name "*.csv" | head -20
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-delivered "$@" > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-delivered "$@" > $OUT/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $OUT/pmc_fetch.log; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-delivered "$@" > $OUT/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -5 $OUT/pmc_write.log; exit 1; }
+python3 $ROOT/tools/summarize_profile.py $OUT $OUT/summary
+# keep the merge-back small: the raw traces are large, the summary is what gets committed
+rm -rf $OUT/trace/*/*_kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Turns one tools/profile_bench.sh output directory into the small files committed under profiles/<tag>/:
+
+  kernel_stats.csv            rocprofv3 --kernel-trace --stats summary of `python3 bench.py ...` (as rocprofv3 wrote it)
+  bench_under_rocprofv3.json  the bench line printed INSIDE that rocprofv3 process (its roofline.kernel_ms_avg are the
+                              same launches as the CSV's average)
+  bench.json                  the plain bench line (its own process)
+  pmc_summary.json            FETCH_SIZE / WRITE_SIZE of the dominant GT kernel from the two --pmc passes (KiB), the shape,
+                              and hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE doubled per
+                              MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of 16-B/lane streaming loads at 64 B)
+
+usage: tools/summarize_profile.py gpurun_out/<tag> [out_dir]
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def last_json_line(path):
+    if not os.path.exists(path):
+        return None
+    for ln in reversed(open(path).read().splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    return None
+
+
+def counter_mean(root, counter):
+    files = glob.glob(os.path.join(root, "*", "*_counter_collection.csv"))
+    per_kernel = {}
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and "pgenhip" in r["Kernel_Name"] and "synth" not in r["Kernel_Name"] and "copy_prefixes" not in r["Kernel_Name"]:
+                per_kernel.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+    if not per_kernel:
+        return None, None
+    name = max(per_kernel, key=lambda k: sum(per_kernel[k]))
+    vals = per_kernel[name]
+    return name, {"launches": len(vals), "mean_KiB": sum(vals) / len(vals), "min_KiB": min(vals), "max_KiB": max(vals)}
+
+
+def main():
+    src = sys.argv[1].rstrip("/")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(src, "summary")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
+    plain = last_json_line(os.path.join(src, "bench.json"))
+    under = last_json_line(os.path.join(src, "trace.log"))
+    for name, obj in (("bench.json", plain), ("bench_under_rocprofv3.json", under)):
+        if obj is not None:
+            json.dump(obj, open(os.path.join(dst, name), "w"), indent=1)
+    kf, fetch = counter_mean(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
+    kw, write = counter_mean(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    ref = plain or under or {}
+    cfg, roof = ref.get("config", {}), ref.get("roofline", {})
+    summary = {
+        "kernel": kf or kw,
+        "shape": {"variants_per_launch": cfg.get("variants_per_launch"), "samples": cfg.get("samples"), "kept": cfg.get("kept_samples"),
+                  "preset": cfg.get("preset"), "distribution": cfg.get("distribution")},
+        "FETCH_SIZE": fetch,
+        "WRITE_SIZE": write,
+        "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch"),
+    }
+    if fetch and write:
+        hbm = int((2.0 * fetch["mean_KiB"] + write["mean_KiB"]) * 1024)
+        summary["hbm_bytes_per_launch"] = hbm
+        if roof.get("algorithmic_bytes_per_launch"):
+            summary["traffic_over_algorithmic"] = hbm / roof["algorithmic_bytes_per_launch"]
+        summary["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                           "(gfx950 counts the 128-B requests of 16-B/lane streaming loads as 64 B)")
+    json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+    print(json.dumps(summary))
+    if stats:
+        for r in csv.DictReader(open(stats[0])):
+            if "pgenhip" in r["Name"] and "synth" not in r["Name"]:
+                print("kernel_stats:", r["Name"][:90], "calls", r["Calls"], "avg ms", float(r["AverageNs"]) / 1e6)
+    if under:
+        print("bench under rocprofv3: kernel_ms_avg", under["roofline"]["kernel_ms_avg"], "frac", under["roofline"]["frac"])
+
+
+if __name__ == "__main__":
+    main()
