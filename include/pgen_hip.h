@@ -204,6 +204,7 @@ typedef enum pgenhip_knob {
     PGENHIP_KNOB_SCAN_BLOCKS_PER_CU = 4, /* segment kernels: resident blocks per CU (default: occupancy API) */
     PGENHIP_KNOB_SCAN_SUPER = 5,         /* three-segment gather kernel: -1 in its measured band (default), 0 never, 1 wherever its ring allows */
     PGENHIP_KNOB_PICK_BATCH_BYTES = 6,   /* short-record pick kernel: text bytes per batch (default 32768) */
+    PGENHIP_KNOB_SCAN_XCD_MAP = 8,       /* segment kernels: 1 (default) all blocks of a row group on one XCD, -1 plain block map */
     PGENHIP_KNOB_RUNS_ROWS = 7           /* RUNS kernel: rows per work item (default: as many as one wide load / one span holds) */
 } pgenhip_knob;
 int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value);

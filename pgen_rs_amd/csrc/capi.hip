@@ -572,6 +572,7 @@ int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value)
             t.scan_super = value;
             break;
         case PGENHIP_KNOB_PICK_BATCH_BYTES: t.pick_batch_bytes = value > 0 ? value : d.pick_batch_bytes; break;
+        case PGENHIP_KNOB_SCAN_XCD_MAP: t.scan_xcd_map = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_RUNS_ROWS: t.runs_rows = value > 0 ? value : d.runs_rows; break;
         default: return fail(PGENHIP_ERR_BAD_ARG, "unknown knob");
     }

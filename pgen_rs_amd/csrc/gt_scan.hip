@@ -98,7 +98,7 @@ constexpr uint32_t kSubSegs = 3;
 constexpr uint32_t kSuperSamples = kSubSegs * kSegSamples;
 
 template <bool HAS_VIDX>
-__global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t n_super, uint32_t row_groups)
+__global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t n_super, uint32_t row_groups, uint32_t xcd_groups)
 {
     __shared__ uint16_t s_idx[kGatherMaxSegCodes + 2];                // rank -> sample index inside the block's 49 152 samples
     __shared__ uint32_t s_live;                                       // bit t: tile t (of 12) holds a kept sample
@@ -108,8 +108,15 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t ss = blockIdx.x % n_super;
-    const uint32_t row_group = blockIdx.x / n_super;
+    // XCD-aware block -> (segment triple, row group) map: the pieces of ONE row are written by the blocks of one row group, and
+    // neighbouring pieces share a 128-B line at every seam.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share
+    // one), so with the plain map b = row_group * n_super + ss the two halves of a seam line come from two different L2s and
+    // reach memory as two partial writes; with row groups a multiple of 8 all blocks of a row group sit on one XCD and that
+    // L2 merges the line.  The first xcd_groups row groups (a multiple of 8) use that map, the rest the plain one.
+    const bool xcd_map = blockIdx.x < xcd_groups * n_super;
+    const uint32_t b_plain = blockIdx.x - xcd_groups * n_super;
+    const uint32_t ss = xcd_map ? (blockIdx.x >> 3) % n_super : b_plain % n_super;
+    const uint32_t row_group = xcd_map ? ((blockIdx.x >> 3) / n_super) * 8u + (blockIdx.x & 7u) : xcd_groups + b_plain / n_super;
 
     // kept samples before each of the block's sub-segment boundaries (global ranks)
     uint32_t kq[kSubSegs + 1];
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
 constexpr uint32_t kPickMaxSegCodes = kSegSamples;             // up to a fully kept segment: 32 KiB of LDS for the table
 
 template <bool HAS_VIDX>
-__global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups)
+__global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups, uint32_t xcd_groups)
 {
     __shared__ uint16_t s_idx[kPickMaxSegCodes + 8];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
@@ -257,8 +264,10 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t seg = blockIdx.x % n_seg;
-    const uint32_t row_group = blockIdx.x / n_seg;
+    const bool xcd_map = blockIdx.x < xcd_groups * n_seg;  // XCD-aware block map: see gt_scan_gather3_kernel
+    const uint32_t b_plain = blockIdx.x - xcd_groups * n_seg;
+    const uint32_t seg = xcd_map ? (blockIdx.x >> 3) % n_seg : b_plain % n_seg;
+    const uint32_t row_group = xcd_map ? ((blockIdx.x >> 3) / n_seg) * 8u + (blockIdx.x & 7u) : xcd_groups + b_plain / n_seg;
     const uint32_t K = a.kept_count;
     const uint32_t seg_k0 = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg]);
     const uint32_t seg_cnt = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg + 1u]) - seg_k0;
@@ -366,28 +375,31 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
     const uint32_t n_seg = (a.sample_count + kSegSamples - 1u) / kSegSamples;
     const uint32_t n_seg_eff = n_seg ? n_seg : 1u;
     const uint64_t groups_needed = ((uint64_t)a.n_variants + kWaves - 1ull) / kWaves;
-    // Two kernels (interleaved A/B in profiles/r01_kernel_sweeps.md):
+    // Two kernels (interleaved A/B, N = 500 000, 60 000 variants, XCD-aware block map on: profiles/r02_kernel_sweeps.md):
     //  * the segment pick kernel — default for every density;
-    //  * the three-segment gather kernel in the one band where it measured ahead (0.8-2 % kept on records of three
-    //    segments or more: config 5; 0.3 % / 0.6 % / 1 % / 2 % kept: pick 1.53 / 1.68 / 1.76 / 2.23 ms, gather 1.62 / 1.75 / 1.72 / 2.14);
+    //  * the three-segment gather kernel in the one band where it still measures ahead, around 1.5 % kept on records of three
+    //    segments or more (0.33 % / 0.5 % / 1 % / 1.5 % / 2 % kept: pick 1.34 / 1.42 / 1.77 / 1.94 / 2.00 ms, gather 1.47 / 1.54 / 1.79 / 1.82 / 2.01);
     //    Tuning::scan_super = 0 / 1 overrides the band (1 still needs the ring precondition).
-    const bool band = n_seg_eff >= kSubSegs && (uint64_t)a.kept_count * 125ull >= (uint64_t)a.sample_count;  // >= 0.8 % kept
+    const bool band = n_seg_eff >= kSubSegs && (uint64_t)a.kept_count * 80ull >= (uint64_t)a.sample_count &&  // >= 1.25 % kept
+                      (uint64_t)a.kept_count * 53ull <= (uint64_t)a.sample_count;                            // <= 1.9 %
     const bool super_kernel = sc.max_super_count <= kGatherMaxSegCodes && (t.scan_super >= 0 ? t.scan_super != 0 : band);
     if (super_kernel) {
-        void (*k3)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t) = gathered(a) ? gt_scan_gather3_kernel<true> : gt_scan_gather3_kernel<false>;
+        void (*k3)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t, uint32_t) = gathered(a) ? gt_scan_gather3_kernel<true> : gt_scan_gather3_kernel<false>;
         const uint32_t n_super = (n_seg_eff + kSubSegs - 1u) / kSubSegs;
         uint64_t groups = (uint64_t)resident_blocks(k3, kThreads, num_cus, t) / n_super;
         if (groups < 1ull) groups = 1ull;
         if (groups > groups_needed) groups = groups_needed;
-        hipLaunchKernelGGL(k3, dim3((uint32_t)(groups * n_super)), dim3(kThreads), 0, stream, a, sc, n_seg_eff, n_super, (uint32_t)groups);
+        const uint32_t xcd_groups = t.scan_xcd_map != 0 ? (uint32_t)(groups & ~7ull) : 0u;
+        hipLaunchKernelGGL(k3, dim3((uint32_t)(groups * n_super)), dim3(kThreads), 0, stream, a, sc, n_seg_eff, n_super, (uint32_t)groups, xcd_groups);
         return hipGetLastError();
     }
-    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t) = gathered(a) ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
+    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t) = gathered(a) ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
     uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus, t) / n_seg_eff;  // floor: never a partial second round
     if (groups < 1ull) groups = 1ull;  // more segments than resident blocks (N > ~16 M samples): rounds are unavoidable
     if (groups > groups_needed) groups = groups_needed;
+    const uint32_t xcd_groups = t.scan_xcd_map != 0 ? (uint32_t)(groups & ~7ull) : 0u;
     const uint32_t grid = (uint32_t)(groups * n_seg_eff);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, sc, n_seg_eff, (uint32_t)groups);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, sc, n_seg_eff, (uint32_t)groups, xcd_groups);
     return hipGetLastError();
 }
 

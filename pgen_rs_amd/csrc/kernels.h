@@ -37,6 +37,7 @@ struct Tuning {
     int scan_blocks_per_cu = 0;    // segment kernels: 0 = occupancy API
     int scan_super = -1;           // three-segment gather kernel: -1 = in its measured band, 0 = never, 1 = wherever its ring allows
     int pick_batch_bytes = 32768;  // short-record pick kernel: text per batch (one store drain per batch)
+    int scan_xcd_map = 1;          // segment kernels: all blocks of a row group on one XCD (seam lines merge in one L2); 0 = plain map
     int runs_rows = 0;             // RUNS mode of the stream kernel: rows per work item (0 = as many as one wide load / one span holds)
 };
 

@@ -15,6 +15,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -34,7 +35,8 @@ def counter_mean(root, counter):
     for f in files:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter and "pgenhip" in r["Kernel_Name"] and "synth" not in r["Kernel_Name"] and "copy_prefixes" not in r["Kernel_Name"]:
-                per_kernel.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+                m = re.match(r"^(.*?_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
+                per_kernel.setdefault(m.group(1) if m else r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     if not per_kernel:
         return None, None
     name = max(per_kernel, key=lambda k: sum(per_kernel[k]))
