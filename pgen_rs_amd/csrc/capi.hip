@@ -433,7 +433,7 @@ static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t re
                     LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
                 else
                     LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
-            } else if (gt_runs_applicable(a))
+            } else if (gt_runs_preferred(a))
                 // short rows, dense records (8 <= N <= 1915): runs of rows as one work item, text staged through LDS in 4-KiB groups
                 // so that every 128-B line leaves whole: 0.68-0.71 of roofline from N = 100 to 1500 where the flat kernel had
                 // 0.42-0.56, the pick kernel 0.31-0.62 and the row-item stream kernel 0.51-0.65 (profiles/r02_kernel_sweeps.md)

@@ -253,6 +253,8 @@ __global__ __launch_bounds__(kThreads) void gt_scan_gather3_kernel(EmitArgs a, S
 // A row piece is >= 4 KiB of text here, so the one store drain per row piece is amortised.  Against the DENSE
 // instantiation of that kernel (> 75 % kept: whole record bytes per step) it was 4-6 % faster as well
 // (0.545 -> 0.566 of roofline at all-but-7 kept).
+// (A 2 048-entry table instantiation for sparse keeps — 4 KiB instead of 32 KiB of LDS, twice the blocks per CU — measured 1-8 %
+// SLOWER at 0.33-5 % kept: this kernel wants few, fat waves; profiles/r02_kernel_sweeps.md.)
 constexpr uint32_t kPickMaxSegCodes = kSegSamples;             // up to a fully kept segment: 32 KiB of LDS for the table
 
 template <bool HAS_VIDX>

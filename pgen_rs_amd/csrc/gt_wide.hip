@@ -44,6 +44,7 @@ struct WideParams {
     uint32_t head;           // out address & 127: the chunk grid is anchored at a 128-B line boundary
     uint32_t n_ranges;       // work-queue kernel: contiguous item ranges with a head word each (1, 2, 4 or 8)
     uint32_t run_rows;       // RUNS mode: rows per work item (B)
+    uint32_t run_rec;        // RUNS mode: bytes per row in the slab (R)
     uint32_t magic;          // RUNS mode: floor(2^32 / S) + 1: o / S = umulhi(o, magic), fixed up by one compare (o < 2^14)
 };
 
@@ -354,7 +355,7 @@ __device__ __forceinline__ Item make_run_item(const EmitArgs &a, const WideParam
 {
     Item it;
     const uint32_t S = (uint32_t)p.row_bytes;
-    const uint32_t R = a.record_size;
+    const uint32_t R = p.run_rec;
     const uint64_t row0 = t * (uint64_t)p.run_rows;
     const uint32_t nrows = (uint32_t)min((uint64_t)p.run_rows, (uint64_t)a.n_variants - row0);
     const uint64_t run_start = row0 * (uint64_t)S;
@@ -402,7 +403,7 @@ template <bool NT>
 __device__ __forceinline__ void emit_run(const EmitArgs &a, const WideParams &p, const Item &it, const uint8_t *slab, uint8_t *stage, uint32_t lane)
 {
     const uint32_t S = (uint32_t)p.row_bytes;
-    const uint32_t R = a.record_size;
+    const uint32_t R = p.run_rec;
     uint8_t *const chunk0 = a.out - p.head;
     const int32_t c_first = (int32_t)it.c_first;
     const uint32_t delta = (uint32_t)it.delta;
@@ -745,6 +746,7 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     // interleaved in one process (profiles/r01_kernel_sweeps.md, chr22 block): 8 ranges 2.058 ms, 4: 2.045, 2: 2.038, 1: 2.039
     p.n_ranges = t.wide_ranges == 1 || t.wide_ranges == 4 || t.wide_ranges == 8 ? (uint32_t)t.wide_ranges : 2u;
     p.run_rows = 0u;
+    p.run_rec = 0u;
     p.magic = 0u;
     // a row owns floor(S/16) or ceil(S/16) chunks (one more for row 0 with an unaligned pointer), and
     // its first span starts up to 63 chunks before them (1-KiB-aligned span grid)
@@ -788,11 +790,15 @@ static uint32_t run_rows_for(const EmitArgs &a)
 bool gt_runs_applicable(const EmitArgs &a)
 {
     // all samples kept, dense records AND dense text (both are then contiguous over a run of rows), rows of >= 33 bytes
-    // (a 16-byte chunk meets at most one '\n') and at least two rows per item (else the row-item kernel is the same thing)
+    // (a 16-byte chunk meets at most one '\n') and at least one whole row per item (N <= 3 831)
     return a.kept_idx == nullptr && a.line_off == nullptr && !gathered(a) && a.sample_count >= 8u &&
            (a.n_variants <= 1 || (a.out_stride == 4ull * a.kept_count + 1ull && a.record_stride == a.record_size)) &&
-           a.work_counters != nullptr && run_rows_for(a) >= 2u;
+           a.work_counters != nullptr && run_rows_for(a) >= 1u;
 }
+
+// AUTO takes the RUNS mode where an item holds at least two rows (N <= 1 915); with one row per item it is the row-item
+// kernel's work item with LDS-staged text, measured against it in profiles/r02_kernel_sweeps.md
+bool gt_runs_preferred(const EmitArgs &a) { return gt_runs_applicable(a) && run_rows_for(a) >= 2u; }
 
 hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream)
 {
@@ -805,6 +811,7 @@ hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     p.n_ranges = t.wide_ranges == 1 || t.wide_ranges == 4 || t.wide_ranges == 8 ? (uint32_t)t.wide_ranges : 2u;
     p.spans_per_row = 1u;
     p.run_rows = t.runs_rows > 0 && (uint32_t)t.runs_rows < run_rows_for(a) ? (uint32_t)t.runs_rows : run_rows_for(a);
+    p.run_rec = a.record_size;
     p.magic = (uint32_t)(0x100000000ull / p.row_bytes) + 1u;
     p.n_items = ((uint64_t)a.n_variants + p.run_rows - 1ull) / p.run_rows;
     const uint64_t need = (p.n_items + 6ull) / 7ull;

@@ -61,6 +61,7 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
 // RUNS mode of the same kernel for SHORT rows (8 <= N <= ~2000, dense records and dense text, no gather): a work item
 // is a run of consecutive rows — one wide load of their contiguous record bytes, their text as one contiguous run.
 bool gt_runs_applicable(const EmitArgs &a);
+bool gt_runs_preferred(const EmitArgs &a);  // what AUTO uses
 hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream);
 
 // Kept-subset segment kernels: number of kept samples before each segment of kScanSegmentSamples samples.

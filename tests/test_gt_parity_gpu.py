@@ -274,7 +274,7 @@ def test_pick_kernel_short_records(n):
                 raise AssertionError(f"n={n} mask={label} v={v} off={out_offset}: {bad.size} bytes differ, first at {bad[:6]}")
 
 
-@pytest.mark.parametrize("n", [8, 9, 10, 11, 33, 61, 100, 255, 256, 300, 301, 302, 303, 500, 1000, 1024, 1399, 1915])
+@pytest.mark.parametrize("n", [8, 9, 10, 11, 33, 61, 100, 255, 256, 300, 301, 302, 303, 500, 1000, 1024, 1399, 1915, 1916, 2504, 3831])
 def test_runs_kernel_short_rows(n):
     """RUNS mode of the stream kernel (short rows: a work item is a run of consecutive rows; the '\n' chunks of a
     run are written in a separate pass).  N from 8 (33-byte rows) up to the largest N with two rows per item,
@@ -305,9 +305,9 @@ def test_runs_kernel_refuses_what_it_cannot_do():
         vidx = torch.arange(10, dtype=torch.int32, device=DEV)
         with pytest.raises(pgen_rs_amd.PgenHipError):   # variant gather
             eng.decode_emit(recs, 10, variant_idx=vidx, out=out, kernel=_capi.KERNEL_RUNS)
-    with pgen_rs_amd.GtEngine(2504, device=0) as eng:   # one row per item: that is the row-item kernel
+    with pgen_rs_amd.GtEngine(5000, device=0) as eng:   # a row of 20 001 bytes does not fit one item (N <= 3 831)
         with pytest.raises(pgen_rs_amd.PgenHipError):
-            eng.decode_emit(torch.zeros(626 * 4, dtype=torch.uint8, device=DEV), 4, kernel=_capi.KERNEL_RUNS)
+            eng.decode_emit(torch.zeros(1250 * 4, dtype=torch.uint8, device=DEV), 4, kernel=_capi.KERNEL_RUNS)
 
 
 def test_work_queue_heads_alternate_across_launches():
