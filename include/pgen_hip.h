@@ -153,7 +153,7 @@ uint64_t pgenhip_gt_row_bytes(const pgenhip_ctx *ctx);
 #define PGENHIP_KERNEL_AUTO 0u
 #define PGENHIP_KERNEL_ROWS 1u   /* general row-tiled kernel (any stride/alignment, list gather) */
 #define PGENHIP_KERNEL_FLAT 2u   /* dense all-samples stream kernel (out_stride == 4N+1) */
-#define PGENHIP_KERNEL_SCAN 3u   /* kept subset on long records: per-segment rank->sample table pick / three-segment gather (N >= 61) */
+#define PGENHIP_KERNEL_SCAN 3u   /* kept subset on long records: per-segment rank->sample table pick (N >= 61) */
 #define PGENHIP_KERNEL_WIDE 4u   /* dense all-samples, wide LDS-staged record loads, one row piece per item (N >= 1024) */
 /* 5u was round 1's stream-span kernel (measured level with WIDE, removed) */
 #define PGENHIP_KERNEL_PICK 6u   /* kept subset on short records (61 <= N <= 4096, K >= 4, dense pitch): output-driven pick through the kept list */
@@ -201,8 +201,8 @@ typedef enum pgenhip_knob {
     PGENHIP_KNOB_WIDE_BLOCKS_PER_CU = 1, /* stream kernel: resident blocks per CU (default: occupancy API) */
     PGENHIP_KNOB_WIDE_RANGES = 2,        /* stream kernel: work-queue ranges 1, 2 (default), 4, 8 */
     PGENHIP_KNOB_FLAT_BLOCKS_PER_CU = 3, /* flat kernel: grid cap per CU (default 64) */
-    PGENHIP_KNOB_SCAN_BLOCKS_PER_CU = 4, /* segment kernels: resident blocks per CU (default: occupancy API) */
-    PGENHIP_KNOB_SCAN_SUPER = 5,         /* three-segment gather kernel: -1 in its measured band (default), 0 never, 1 wherever its ring allows */
+    PGENHIP_KNOB_SCAN_BLOCKS_PER_CU = 4, /* segment kernel: resident blocks per CU (default: 2 from ~0.6 % kept, else the occupancy API's 3) */
+    /* 5 was the band override of round 1's three-segment gather kernel (removed) */
     PGENHIP_KNOB_PICK_BATCH_BYTES = 6,   /* short-record pick kernel: text bytes per batch (default 32768) */
     PGENHIP_KNOB_SCAN_XCD_MAP = 8,       /* segment kernels: 1 (default) all blocks of a row group on one XCD, -1 plain block map */
     PGENHIP_KNOB_RUNS_ROWS = 7           /* RUNS kernel: rows per work item (default: as many as one wide load / one span holds) */

@@ -48,7 +48,6 @@ KNOB_WIDE_BLOCKS_PER_CU = 1
 KNOB_WIDE_RANGES = 2
 KNOB_FLAT_BLOCKS_PER_CU = 3
 KNOB_SCAN_BLOCKS_PER_CU = 4
-KNOB_SCAN_SUPER = 5
 KNOB_PICK_BATCH_BYTES = 6
 KNOB_RUNS_ROWS = 7
 KNOB_SCAN_XCD_MAP = 8

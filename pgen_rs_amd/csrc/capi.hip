@@ -25,7 +25,6 @@ struct pgenhip_ctx {
     uint32_t *d_kept = nullptr;
     uint32_t *d_seg_rank = nullptr;    // segment kernels: kept samples before each segment
     uint32_t max_seg_count = 0;        // segment kernels: most kept samples in one segment
-    uint32_t max_super_count = 0;      // segment kernels: most kept samples in an aligned triple of segments
     uint64_t *d_work = nullptr;        // stream kernel: ring of PGENHIP_LAUNCHES_IN_FLIGHT counter blocks (8 work-queue heads 128 B apart + an exit counter)
     uint32_t launch_seq = 0;           // next counter block of the ring
     bool work_dirty = false;           // a launch failed: counters may be non-zero, re-zero the ring before the next launch
@@ -298,8 +297,6 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
                 ctx->max_seg_count = std::max(ctx->max_seg_count, seg_rank[g + 1u]);
                 seg_rank[g + 1u] += seg_rank[g];
             }
-            for (uint32_t g = 0; g < n_seg_eff; g += 3u)
-                ctx->max_super_count = std::max(ctx->max_super_count, seg_rank[std::min(g + 3u, n_seg_eff)] - seg_rank[g]);
             if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_seg_rank), seg_rank.size() * sizeof(uint32_t))) != hipSuccess) { rc = fail_hip(e, "hipMalloc(segment ranks)"); break; }
             if ((e = hipMemcpy(ctx->d_seg_rank, seg_rank.data(), seg_rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(segment ranks)"); break; }
         }
@@ -420,7 +417,7 @@ static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t re
     rc = claim_counters(ctx, a);
     if (rc) return rc;
     const Tuning &t = ctx->tune;
-    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
+    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count};
 
     switch (flags & PGENHIP_KERNEL_MASK) {
         case PGENHIP_KERNEL_AUTO:
@@ -512,7 +509,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
     rc = claim_counters(ctx, a);
     if (rc) return rc;
     const Tuning &t = ctx->tune;
-    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count, ctx->max_super_count};
+    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count};
     switch (flags) {
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;
@@ -567,10 +564,6 @@ int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value)
             break;
         case PGENHIP_KNOB_FLAT_BLOCKS_PER_CU: t.flat_blocks_per_cu = value > 0 ? value : d.flat_blocks_per_cu; break;
         case PGENHIP_KNOB_SCAN_BLOCKS_PER_CU: t.scan_blocks_per_cu = value > 0 ? value : d.scan_blocks_per_cu; break;
-        case PGENHIP_KNOB_SCAN_SUPER:
-            if (value < -1 || value > 1) return fail(PGENHIP_ERR_BAD_ARG, "scan_super must be -1, 0 or 1");
-            t.scan_super = value;
-            break;
         case PGENHIP_KNOB_PICK_BATCH_BYTES: t.pick_batch_bytes = value > 0 ? value : d.pick_batch_bytes; break;
         case PGENHIP_KNOB_SCAN_XCD_MAP: t.scan_xcd_map = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_RUNS_ROWS: t.runs_rows = value > 0 ? value : d.runs_rows; break;

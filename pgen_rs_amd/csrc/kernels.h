@@ -34,8 +34,7 @@ struct Tuning {
     int wide_blocks_per_cu = 0;    // stream kernel: 0 = what the occupancy API says is resident
     int wide_ranges = 2;           // stream kernel: work-queue ranges (1, 2, 4 or 8)
     int flat_blocks_per_cu = 64;   // flat kernel: grid cap
-    int scan_blocks_per_cu = 0;    // segment kernels: 0 = occupancy API
-    int scan_super = -1;           // three-segment gather kernel: -1 = in its measured band, 0 = never, 1 = wherever its ring allows
+    int scan_blocks_per_cu = 0;    // segment kernel: 0 = the measured rule (2 from ~0.6 % kept, else what the occupancy API says)
     int pick_batch_bytes = 32768;  // short-record pick kernel: text per batch (one store drain per batch)
     int scan_xcd_map = 1;          // segment kernels: all blocks of a row group on one XCD (seam lines merge in one L2); 0 = plain map
     int runs_rows = 0;             // RUNS mode of the stream kernel: rows per work item (0 = as many as one wide load / one span holds)
@@ -69,7 +68,6 @@ constexpr uint32_t kScanSegmentSamples = 16384u;
 struct ScanArgs {
     const uint32_t *seg_rank;    // device; n_segments + 1 entries
     uint32_t max_seg_count;      // most kept samples in any one segment
-    uint32_t max_super_count;    // most kept samples in any aligned triple of segments (picks the three-segment gather kernel)
 };
 hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t, int num_cus, hipStream_t stream);
 

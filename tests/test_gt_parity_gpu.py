@@ -194,21 +194,19 @@ def test_subset_with_strides_offsets_and_gather():
         assert (got == exp).all(), f"kernel {kern}"
 
 
-@pytest.mark.parametrize("batch", ["super", "pick"])
-def test_scan_kernels_many_rows_per_wave(batch):
-    """Sparse-keep scan kernels with many rows per wave: the gather kernel's code ring is reused
-    across batches (12 rows each), rows end mid-triple, segments with no kept sample at the front
-    and at the back (the last segment then only owes the '\n'), a locally dense mask (falls back
-    to the per-row kernel) and a gapped variant list."""
-    tune = {_capi.KNOB_SCAN_BLOCKS_PER_CU: 1,  # few blocks -> ~15-25 rows per wave
-            _capi.KNOB_SCAN_SUPER: 1 if batch == "super" else 0}  # three-segment gather where its ring allows / segment pick
+@pytest.mark.parametrize("per_cu", [1, 2])
+def test_scan_kernels_many_rows_per_wave(per_cu):
+    """The segment kernel with many rows per wave (1 or 2 blocks per CU): register double-buffering over many
+    rows, segments with no kept sample at the front and at the back (the last segment then only owes the
+    '\n'), a locally dense mask and a gapped variant list."""
+    tune = {_capi.KNOB_SCAN_BLOCKS_PER_CU: per_cu}  # few blocks -> ~8-25 rows per wave
     n = 40000  # three 16 384-sample segments, the last one partial
     r = oracle.variant_record_size(n)
     rng = np.random.default_rng(77)
     masks = {
         "1pct": np.sort(rng.choice(n, size=n // 100, replace=False)),
-        "5pct": np.sort(rng.choice(n, size=n * 5 // 100, replace=False)),      # ~820 per segment: 3 rows per batch
-        "11pct": np.sort(rng.choice(n, size=n * 11 // 100, replace=False)),    # too many for the gather kernel's ring: per-row kernel
+        "5pct": np.sort(rng.choice(n, size=n * 5 // 100, replace=False)),      # ~820 per segment
+        "11pct": np.sort(rng.choice(n, size=n * 11 // 100, replace=False)),    # ~1 800 per segment
         "front_empty": np.sort(rng.choice(np.arange(16384, n), size=300, replace=False)),
         "back_empty": np.sort(rng.choice(np.arange(0, 32768), size=300, replace=False)),
         "only_middle": np.sort(rng.choice(np.arange(16384, 32768), size=500, replace=False)),
@@ -223,13 +221,13 @@ def test_scan_kernels_many_rows_per_wave(batch):
             want = oracle.decode_emit(recs, v, n, kept_idx=kept, variant_idx=idx).reshape(v, -1)
             got, k = run_engine(recs, v, n, kept=kept, kernel=_capi.KERNEL_SCAN, variant_idx=idx, tune=tune)
             exp = expect_buffer(want, v, k, 4 * k + 1, 0, got.size)
-            assert (got == exp).all(), f"mask {label} v={v} batch={batch}"
+            assert (got == exp).all(), f"mask {label} v={v} per_cu={per_cu}"
 
 
 @pytest.mark.parametrize("n", [16384, 16385, 49152, 49153, 70001, 98304, 100003, 147457])
 def test_sparse_subsets_segment_triples(n):
     """Sparse keeps where the number of 16 384-sample segments is 1..10, i.e. the last block of the
-    three-segment gather kernel owns one, two or three segments and the record ends in any of its
+    last block of a row group owns a partial segment and the record ends in any of its
     tiles; kept samples include the very first and the very last sample."""
     rng = np.random.default_rng(900 + n)
     v = 41
@@ -471,8 +469,8 @@ def test_emit_lines_stream_kernel(n, v, kernel):
 @pytest.mark.parametrize("n,frac", [(2504, 0.01), (2504, 0.5), (40000, 0.01), (40000, 0.3), (40000, 0.9), (120000, 0.004), (120000, 0.02)])
 @pytest.mark.parametrize("kernel", [_capi.KERNEL_AUTO, _capi.KERNEL_SCAN, _capi.KERNEL_ROWS, _capi.KERNEL_PICK])
 def test_emit_lines_kept_subsets(n, frac, kernel):
-    """Full lines with a sample filter: every scan-family kernel (per-row, dense, segment pick, one- and
-    three-segment gather, chosen by density and N) writes its GT segments behind the prefixes and
+    """Full lines with a sample filter: the subset kernel AUTO picks for the density and N (short-record pick,
+    segment pick, list gather) writes its GT segments behind the prefixes and
     the prefix kernel fills those in; same bytes as the general kernel and the oracle, with a
     gapped variant list and sentinel bytes around the output."""
     if kernel == _capi.KERNEL_PICK and n > 4096:
@@ -653,14 +651,14 @@ def test_config3_full_size_100k_by_500k(v):
 
 
 @pytest.mark.parametrize("v", [100_000, 125_000])
-@pytest.mark.parametrize("batch", ["super", "pick"])
-def test_config5_geometry_500k_samples_keep_1pct(batch, v):
+@pytest.mark.parametrize("xcd_map", [1, -1])
+def test_config5_geometry_500k_samples_keep_1pct(xcd_map, v):
     """BASELINE config 5's per-GPU geometry in ONE launch: 100 000 variants x 500 000 samples and the
     125 000-variant shard each of 8 GPUs owns (12.5 / 15.6 GB of records, offsets beyond 2^32), the 1 %
     splitmix keep mask of SURVEY 8(d) (4 940 kept -> 19 761-byte rows, 1.98 / 2.47 GB of text).
-    Three-segment gather and segment pick kernels: LF / TAB / slash columns over the whole buffer, byte
+    The segment pick kernel with the XCD-aware and the plain block map: LF / TAB / slash columns over the whole buffer, byte
     equality with the oracle on rows from the start, the reference's u32-wrap boundary, the middle and
-    the end, and equality of the two kernels' whole outputs through a checksum of checksums."""
+    the end, and equality of the two launches' whole outputs through a checksum of checksums."""
     n = 500_000
     free, _total = torch.cuda.mem_get_info(0)
     if free < v * 125_000 + (8 << 30):
@@ -669,7 +667,7 @@ def test_config5_geometry_500k_samples_keep_1pct(batch, v):
     k = int(kept.size)
     row = 4 * k + 1
     with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
-        eng.tune(_capi.KNOB_SCAN_SUPER, 1 if batch == "super" else 0)
+        eng.tune(_capi.KNOB_SCAN_XCD_MAP, xcd_map)
         recs = eng.synth_records(v)
         out = eng.decode_emit(recs, v, kernel=_capi.KERNEL_SCAN)
         eng.wait()
