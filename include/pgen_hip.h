@@ -205,6 +205,8 @@ typedef enum pgenhip_knob {
     /* 5 was the band override of round 1's three-segment gather kernel (removed) */
     PGENHIP_KNOB_PICK_BATCH_BYTES = 6,   /* short-record pick kernel: text bytes per batch (default 32768) */
     PGENHIP_KNOB_SCAN_XCD_MAP = 8,       /* segment kernels: 1 (default) all blocks of a row group on one XCD, -1 plain block map */
+    PGENHIP_KNOB_SCAN_TWO_PASS = 9,      /* sparse keeps on long records: 1 (default) compact pass + all-samples pass, -1 single-pass segment kernel */
+    PGENHIP_KNOB_SCAN_CHUNK_ROWS = 10,   /* two-pass path: rows per chunk (default: as many as the 64-MiB compact scratch holds) */
     PGENHIP_KNOB_RUNS_ROWS = 7           /* RUNS kernel: rows per work item (default: as many as one wide load / one span holds) */
 } pgenhip_knob;
 int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value);

@@ -51,6 +51,8 @@ KNOB_SCAN_BLOCKS_PER_CU = 4
 KNOB_PICK_BATCH_BYTES = 6
 KNOB_RUNS_ROWS = 7
 KNOB_SCAN_XCD_MAP = 8
+KNOB_SCAN_TWO_PASS = 9
+KNOB_SCAN_CHUNK_ROWS = 10
 
 
 

@@ -25,6 +25,8 @@ struct pgenhip_ctx {
     uint32_t *d_kept = nullptr;
     uint32_t *d_seg_rank = nullptr;    // segment kernels: kept samples before each segment
     uint32_t max_seg_count = 0;        // segment kernels: most kept samples in one segment
+    uint8_t *d_compact = nullptr;      // two-pass path for sparse keeps on long records: compact records of one chunk of rows
+    size_t compact_bytes = 0;
     uint64_t *d_work = nullptr;        // stream kernel: ring of PGENHIP_LAUNCHES_IN_FLIGHT counter blocks (8 work-queue heads 128 B apart + an exit counter)
     uint32_t launch_seq = 0;           // next counter block of the ring
     bool work_dirty = false;           // a launch failed: counters may be non-zero, re-zero the ring before the next launch
@@ -63,6 +65,17 @@ int bind(const pgenhip_ctx *ctx)
     if (!ctx) return fail(PGENHIP_ERR_BAD_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     return PGENHIP_OK;
+}
+
+// Sparse keeps on long records (BASELINE config 5: 1 % of 500 000 samples) go through TWO passes: the segment kernel writes each
+// row's COMPACT record (the K kept codes packed like a mode-0x02 record of K samples: 41-byte pieces instead of 656-byte pieces of
+// text per row and segment) and the all-samples kernels turn those into text with whole-line stores.  Worth it while the text is
+// small against the records.  Measured band (N = 500 000, profiles/r02_kernel_sweeps.md): 0.5 % kept -2 %, 0.65 % +4 %, 1 % +15 %,
+// 2 % +11 %, 4 % +7 %, 5 % level, 10 % -4 %  ->  0.6 % .. 4.5 % kept.
+bool two_pass_shape(uint32_t sample_count, uint32_t kept_count)
+{
+    return sample_count > 4096u && kept_count >= 8u && (uint64_t)kept_count * 170ull >= (uint64_t)sample_count &&
+           (uint64_t)kept_count * 22ull <= (uint64_t)sample_count;
 }
 
 constexpr size_t kWorkBlockBytes = 9u * 128u;  // 8 heads 128 B apart + the exit counter
@@ -299,6 +312,13 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
             }
             if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_seg_rank), seg_rank.size() * sizeof(uint32_t))) != hipSuccess) { rc = fail_hip(e, "hipMalloc(segment ranks)"); break; }
             if ((e = hipMemcpy(ctx->d_seg_rank, seg_rank.data(), seg_rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(segment ranks)"); break; }
+            // two-pass path (sparse keeps on long records): a fixed 64-MiB scratch for the compact records of one chunk of rows (config
+            // 5's per-GPU shard, 125 000 rows x 1 235 bytes, is three chunks: measured 1 % ahead of one 154-MB chunk — the scratch
+            // stays in the 256-MiB Infinity Cache between the two passes); allocated here so that no launch ever allocates
+            if (two_pass_shape(sample_count, kept_count)) {
+                ctx->compact_bytes = 64u << 20;
+                if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_compact), ctx->compact_bytes)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(compact records)"); break; }
+            }
         }
     } while (0);
     if (rc != PGENHIP_OK) {
@@ -319,6 +339,7 @@ int pgenhip_destroy(pgenhip_ctx *ctx)
     if (ctx->d_kept) (void)hipFree(ctx->d_kept);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_seg_rank) (void)hipFree(ctx->d_seg_rank);
+    if (ctx->d_compact) (void)hipFree(ctx->d_compact);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -400,6 +421,93 @@ static bool very_sparse(const pgenhip_ctx *ctx)
     return ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 300ull <= ctx->sample_count;
 }
 
+// AUTO for all samples kept, GT segments at a.out + j * a.out_stride
+static int dispatch_all_samples(pgenhip_ctx *ctx, const EmitArgs &a)
+{
+    const Tuning &t = ctx->tune;
+    if (gt_runs_preferred(a))
+        // short rows, dense records (8 <= N <= 1915): runs of rows as one work item, text staged through LDS in 4-KiB groups
+        // so that every 128-B line leaves whole: 0.68-0.71 of roofline from N = 100 to 1500 where the flat kernel had
+        // 0.42-0.56, the pick kernel 0.31-0.62 and the row-item stream kernel 0.51-0.65 (profiles/r02_kernel_sweeps.md)
+        LAUNCH_TRY(launch_gt_runs(a, t, ctx->num_cus, ctx->stream));
+    else if (gt_pick_applicable(a) && a.sample_count >= 400u && a.sample_count < 1400u)
+        // short rows that are gathered or padded (no contiguous runs): batches of rows through gt_pick.hip with the identity for a table
+        LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
+    else if (gt_wide_applicable(a))
+        LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
+    else if (gt_flat_applicable(a))
+        LAUNCH_TRY(launch_gt_flat(a, t, ctx->num_cus, ctx->stream));
+    else
+        LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+    return PGENHIP_OK;
+}
+
+// AUTO for all samples kept, full lines (a.line_off / a.prefix_off set)
+static int dispatch_all_samples_lines(pgenhip_ctx *ctx, const EmitArgs &a)
+{
+    const Tuning &t = ctx->tune;
+    if (gt_wide_lines_applicable(a)) {
+        // rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place behind their prefixes (+ a small prefix copy)
+        LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
+    } else if (gt_pick_applicable(a)) {
+        // shorter rows: the pick kernel (identity for a table) flushes each parked row behind its prefix
+        LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
+        LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+    } else {
+        LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+    }
+    return PGENHIP_OK;
+}
+
+// Two passes for sparse keeps on long records, chunk by chunk of as many rows as the compact scratch holds: (1) the segment kernel
+// compacts each row's kept codes into a K-sample record, (2) the all-samples dispatch above turns those records into text.
+static bool two_pass(const pgenhip_ctx *ctx, const EmitArgs &a)
+{
+    return ctx->tune.scan_two_pass != 0 && ctx->d_compact != nullptr && a.kept_idx != nullptr && a.record_size >= 16u &&
+           (a.line_off != nullptr || a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull);
+}
+
+static int dispatch_two_pass(pgenhip_ctx *ctx, const EmitArgs &a, const ScanArgs &sc)
+{
+    const uint32_t rc_bytes = (a.kept_count + 3u) / 4u;
+    uint64_t chunk_rows = std::max<uint64_t>(1ull, ctx->compact_bytes / rc_bytes);
+    if (ctx->tune.scan_chunk_rows > 0) chunk_rows = std::min<uint64_t>(chunk_rows, (uint64_t)ctx->tune.scan_chunk_rows);
+    for (uint64_t row0 = 0; row0 < a.n_variants; row0 += chunk_rows) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(chunk_rows, (uint64_t)a.n_variants - row0);
+        EmitArgs c = a;  // pass 1: this chunk's rows -> compact records
+        if (a.record_off) c.record_off = a.record_off + row0;
+        else if (a.variant_idx) c.variant_idx = a.variant_idx + row0;
+        else c.records = a.records + row0 * a.record_stride;
+        c.n_variants = n;
+        c.out = ctx->d_compact;
+        c.out_stride = rc_bytes;
+        c.prefix_blob = nullptr;
+        c.prefix_off = nullptr;
+        c.line_off = nullptr;
+        LAUNCH_TRY(launch_gt_scan(c, sc, ctx->tune, ctx->num_cus, ctx->stream, true));
+        EmitArgs d = a;  // pass 2: a block of n mode-0x02 records of K samples, all of them kept
+        d.records = ctx->d_compact;
+        d.record_stride = rc_bytes;
+        d.variant_idx = nullptr;
+        d.record_off = nullptr;
+        d.n_variants = n;
+        d.sample_count = a.kept_count;
+        d.record_size = rc_bytes;
+        d.kept_idx = nullptr;
+        if (a.line_off) {
+            d.prefix_off = a.prefix_off + row0;  // offsets are absolute: the same blob and output base
+            d.line_off = a.line_off + row0;
+            const int rc = dispatch_all_samples_lines(ctx, d);
+            if (rc) return rc;
+        } else {
+            d.out = a.out + row0 * a.out_stride;
+            const int rc = dispatch_all_samples(ctx, d);
+            if (rc) return rc;
+        }
+    }
+    return PGENHIP_OK;
+}
+
 static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride, const uint32_t *d_variant_idx,
                             const uint64_t *d_record_off, uint32_t n_variants, void *d_out, uint64_t out_stride, uint32_t flags)
 {
@@ -422,28 +530,16 @@ static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t re
     switch (flags & PGENHIP_KERNEL_MASK) {
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;  // `--include-sam` that keeps everybody: same bytes, the all-samples kernels
-            if (a.kept_idx != nullptr) {
-                if (gt_pick_applicable(a))
-                    // short records (the 1000 Genomes shape with a sample filter): output-driven pick, any density
-                    LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
-                else if (very_sparse(ctx) || ctx->record_size < 16u)
-                    LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
-                else
-                    LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
-            } else if (gt_runs_preferred(a))
-                // short rows, dense records (8 <= N <= 1915): runs of rows as one work item, text staged through LDS in 4-KiB groups
-                // so that every 128-B line leaves whole: 0.68-0.71 of roofline from N = 100 to 1500 where the flat kernel had
-                // 0.42-0.56, the pick kernel 0.31-0.62 and the row-item stream kernel 0.51-0.65 (profiles/r02_kernel_sweeps.md)
-                LAUNCH_TRY(launch_gt_runs(a, t, ctx->num_cus, ctx->stream));
-            else if (gt_pick_applicable(a) && ctx->sample_count >= 400u && ctx->sample_count < 1400u)
-                // short rows that are gathered or padded (no contiguous runs): batches of rows through gt_pick.hip with the identity for a table
+            if (a.kept_idx == nullptr) return dispatch_all_samples(ctx, a);
+            if (gt_pick_applicable(a))
+                // short records (the 1000 Genomes shape with a sample filter): output-driven pick, any density
                 LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
-            else if (gt_wide_applicable(a))
-                LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
-            else if (gt_flat_applicable(a))
-                LAUNCH_TRY(launch_gt_flat(a, t, ctx->num_cus, ctx->stream));
-            else
+            else if (very_sparse(ctx) || ctx->record_size < 16u)
                 LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
+            else if (two_pass(ctx, a))
+                return dispatch_two_pass(ctx, a, sc);
+            else
+                LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_ROWS:
             LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
@@ -513,16 +609,14 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
     switch (flags) {
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;
-            // all samples kept and rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place
-            // behind their prefixes (+ a small prefix copy); otherwise the general kernel assembles whole lines
-            if (gt_wide_lines_applicable(a)) {
-                LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
-            } else if (gt_pick_applicable(a)) {
-                // short records (kept subset, or all samples on rows under 4 KiB): the pick kernel flushes each parked row behind its prefix
+            if (a.kept_idx == nullptr) return dispatch_all_samples_lines(ctx, a);
+            if (gt_pick_applicable(a)) {
+                // kept subset on short records: the pick kernel flushes each parked row behind its prefix
                 LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
                 LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
-            } else if (a.kept_idx != nullptr && ctx->record_size >= 16u && !very_sparse(ctx)) {
-                // kept subset: the segment kernels write each GT segment behind its prefix, the prefix kernel the rest
+            } else if (ctx->record_size >= 16u && !very_sparse(ctx)) {
+                if (two_pass(ctx, a)) return dispatch_two_pass(ctx, a, sc);
+                // kept subset: the segment kernel writes each GT segment behind its prefix, the prefix kernel the rest
                 LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
                 LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             } else {
@@ -566,6 +660,8 @@ int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value)
         case PGENHIP_KNOB_SCAN_BLOCKS_PER_CU: t.scan_blocks_per_cu = value > 0 ? value : d.scan_blocks_per_cu; break;
         case PGENHIP_KNOB_PICK_BATCH_BYTES: t.pick_batch_bytes = value > 0 ? value : d.pick_batch_bytes; break;
         case PGENHIP_KNOB_SCAN_XCD_MAP: t.scan_xcd_map = value < 0 ? 0 : 1; break;
+        case PGENHIP_KNOB_SCAN_CHUNK_ROWS: t.scan_chunk_rows = value > 0 ? value : d.scan_chunk_rows; break;
+        case PGENHIP_KNOB_SCAN_TWO_PASS: t.scan_two_pass = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_RUNS_ROWS: t.runs_rows = value > 0 ? value : d.runs_rows; break;
         default: return fail(PGENHIP_ERR_BAD_ARG, "unknown knob");
     }

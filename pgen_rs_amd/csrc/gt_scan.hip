@@ -64,7 +64,13 @@ constexpr uint32_t kStageBytes = kSegSamples / 4u;                   // one row'
 // SLOWER at 0.33-5 % kept: this kernel wants few, fat waves; profiles/r02_kernel_sweeps.md.)
 constexpr uint32_t kPickMaxSegCodes = kSegSamples;             // up to a fully kept segment: 32 KiB of LDS for the table
 
-template <bool HAS_VIDX>
+// COMPACT instantiation (first pass of the two-pass path for sparse keeps, launch_gt_scan): instead of text the block writes
+// its part of each row's COMPACT record to a.out + j * a.out_stride — the K kept codes packed four to a byte exactly like a
+// mode-0x02 record of K samples (src/pfile.rs:171-175 applied here; :177-190 by the all-samples kernels in the second pass).
+// Byte b of a compact record belongs to the segment that owns rank 4b: a block writes bytes ceil(k0/4) .. ceil(k1/4)-1 of its
+// rank slice [k0, k1) and fetches the up to three ranks behind k1 that share its last byte straight from the record (their
+// samples live in later segments) — no byte is written twice, nothing needs zeroing.
+template <bool HAS_VIDX, bool COMPACT = false>
 __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups, uint32_t xcd_groups)
 {
     __shared__ uint16_t s_idx[kPickMaxSegCodes + 8];
@@ -93,9 +99,18 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
 
     if (seg_cnt == 0u) {
         // nothing of this segment is kept; the last segment still owes every row its '\n' (:190)
-        if (last_seg)
+        if (!COMPACT && last_seg)
             for (uint64_t n = lane; n < rows; n += 64ull) row_text(a, j0 + n * row_step)[4ull * K] = (uint8_t)'\n';
         return;
+    }
+    // COMPACT: bytes of the compact record this block owns, and the ranks behind its slice that share its last byte
+    const uint32_t seg_k1 = seg_k0 + seg_cnt;
+    const uint32_t cb0 = (seg_k0 + 3u) >> 2, cb1 = (seg_k1 + 3u) >> 2;
+    const uint32_t n_foreign = COMPACT ? min((cb1 << 2) - seg_k1, K - seg_k1) : 0u;   // 0 .. 3
+    uint32_t f_smp = 0u;  // lane i < n_foreign: sample of rank seg_k1 + i
+    if (COMPACT) {
+        if (cb0 == cb1) return;  // every rank of the slice sits in a byte an earlier segment owns
+        if (lane < n_foreign) f_smp = a.kept_idx[seg_k1 + lane];
     }
     for (uint32_t r = tid; r < seg_cnt + 8u; r += (uint32_t)kThreads)
         s_idx[r] = r < seg_cnt ? (uint16_t)(a.kept_idx[seg_k0 + r] - seg * kSegSamples) : (uint16_t)0;  // 8 entries of slack for the flush's fifth code
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     const uint32_t tail_b = tail_t * 1024u + lane * 16u;
     const uint32_t tail_off = min(tail_b, R - 16u);
     const uint32_t tail_shift = tail_b + 16u <= R ? 0u : min(tail_b - (R - 16u), 16u);
-    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg]) {
+    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg], uint32_t &fbyte) {
         const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
         const uint8_t *__restrict__ rec = HAS_VIDX ? gathered_record(a, row) : a.records + row * a.record_stride;
         const uint8_t *__restrict__ sub = rec + (uint64_t)tile0 * 1024u;
@@ -119,8 +134,9 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
             const uint8_t *src16 = tile0 + t < tail_t ? sub + lane * 16u + t * 1024u : rec + tail_off;
             __builtin_memcpy(&dst[t], src16, 16);
         }
+        if (COMPACT && lane < n_foreign) fbyte = rec[f_smp >> 2];  // the record byte of a rank behind the slice (a later segment's sample)
     };
-    auto emit_row = [&](uint64_t n, const v4u(&w)[kTilesPerSeg]) {
+    auto emit_row = [&](uint64_t n, const v4u(&w)[kTilesPerSeg], uint32_t fbyte) {
         // park the row's segment bytes (segment byte b at stage[b])
 #pragma unroll
         for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
@@ -135,6 +151,30 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (COMPACT) {
+            // lane <-> compact byte b = ranks 4b .. 4b+3 (src/pfile.rs:171-175: rank -> sample -> bits 2*(s%4) of byte s/4)
+            uint8_t *const crow = a.out + (j0 + n * row_step) * a.out_stride;
+            // the foreign ranks' codes, wave-uniform: rank seg_k1 + i sits at bits 2 * ((seg_k1 + i) & 3) of the last owned byte
+            uint32_t f_bits = 0u;
+            const uint32_t f_code = (fbyte >> ((f_smp & 3u) * 2u)) & 3u;
+            for (uint32_t i = 0; i < n_foreign; i++)
+                f_bits |= (uint32_t)__builtin_amdgcn_readlane((int)f_code, (int)i) << (2u * ((seg_k1 + i) & 3u));
+            for (uint32_t b = cb0 + lane; b < cb1; b += 64u) {
+                uint32_t byte = 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t r = 4u * b + j - seg_k0;           // rank inside the slice (>= 0: b >= ceil(seg_k0 / 4))
+                    const uint32_t s16 = s_idx[min(r, seg_cnt)];      // entries behind the slice are 0 (slack)
+                    const uint32_t code = ((uint32_t)stage[s16 >> 2] >> ((s16 & 3u) * 2u)) & 3u;
+                    byte |= (r < seg_cnt ? code : 0u) << (2u * j);
+                }
+                if (b + 1u == cb1) byte |= f_bits;
+                crow[b] = (uint8_t)byte;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
         uint8_t *const row_out = row_text(a, j0 + n * row_step);
         const uint64_t lo_emit = 4ull * seg_k0;
         const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
@@ -156,15 +196,16 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     // two register buffers, the loop unrolled by two: the next row's loads are in flight while this row's text goes out
     // (three buffers, re-loaded three rows ahead, measured no better: 3.20-3.35 vs 3.03-3.20 ms on the config-5 geometry)
     v4u b0[kTilesPerSeg], b1[kTilesPerSeg];
-    load_row(0ull, b0);
+    uint32_t f0 = 0u, f1 = 0u;
+    load_row(0ull, b0, f0);
     for (uint64_t n = 0;;) {
         landed(b0);
-        load_row(n + 1ull, b1);
-        emit_row(n, b0);
+        load_row(n + 1ull, b1, f1);
+        emit_row(n, b0, f0);
         if (++n == rows) break;
         landed(b1);
-        load_row(n + 1ull, b0);
-        emit_row(n, b1);
+        load_row(n + 1ull, b0, f0);
+        emit_row(n, b1, f1);
         if (++n == rows) break;
     }
 }
@@ -183,7 +224,7 @@ static uint32_t resident_blocks(Kern kern, int threads, int num_cus, const Tunin
     return (uint32_t)per_cu * (uint32_t)num_cus;
 }
 
-hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t, int num_cus, hipStream_t stream)
+hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t, int num_cus, hipStream_t stream, bool compact)
 {
     if (a.n_variants == 0) return hipSuccess;
     if (a.kept_idx == nullptr) return hipErrorInvalidValue;
@@ -194,8 +235,12 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
     // two blocks per CU the pick kernel is ahead there too: 1.5 % kept 1.85 vs 1.99 ms, profiles/r02_kernel_sweeps.md).
     // Blocks per CU: the occupancy API says 3 (32 KiB table + 16 KiB of stages); from ~0.6 % kept upwards 2 measure the same or
     // better (+5-9 % at 1-3 % kept, level from 30 %), below that 3 do (the kernel is then a pure record reader).
-    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t) = gathered(a) ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
-    const int preferred = (uint64_t)a.kept_count * 170ull >= (uint64_t)a.sample_count ? 2 : 0;
+    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t);
+    if (compact)  // first pass of the two-pass path: a.out / a.out_stride address the compact records (ceil(K / 4) bytes per row)
+        kern = gathered(a) ? gt_scan_pick_kernel<true, true> : gt_scan_pick_kernel<false, true>;
+    else
+        kern = gathered(a) ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
+    const int preferred = !compact && (uint64_t)a.kept_count * 170ull >= (uint64_t)a.sample_count ? 2 : 0;
     uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus, t, preferred) / n_seg_eff;  // floor: never a partial second round
     if (groups < 1ull) groups = 1ull;  // more segments than resident blocks (N > ~16 M samples): rounds are unavoidable
     if (groups > groups_needed) groups = groups_needed;

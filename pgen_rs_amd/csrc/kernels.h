@@ -37,6 +37,8 @@ struct Tuning {
     int scan_blocks_per_cu = 0;    // segment kernel: 0 = the measured rule (2 from ~0.6 % kept, else what the occupancy API says)
     int pick_batch_bytes = 32768;  // short-record pick kernel: text per batch (one store drain per batch)
     int scan_xcd_map = 1;          // segment kernels: all blocks of a row group on one XCD (seam lines merge in one L2); 0 = plain map
+    int scan_chunk_rows = 0;       // two-pass path: rows per chunk (0 = as many as the 64-MiB compact scratch holds; tests force small chunks)
+    int scan_two_pass = 1;         // sparse keeps on long records: compact pass + all-samples pass (0 = single-pass segment kernel)
     int runs_rows = 0;             // RUNS mode of the stream kernel: rows per work item (0 = as many as one wide load / one span holds)
 };
 
@@ -69,7 +71,9 @@ struct ScanArgs {
     const uint32_t *seg_rank;    // device; n_segments + 1 entries
     uint32_t max_seg_count;      // most kept samples in any one segment
 };
-hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t, int num_cus, hipStream_t stream);
+// compact = true: write each row's COMPACT record (the K kept codes packed like a mode-0x02 record of K samples) to a.out + j * a.out_stride
+// instead of text: the first pass of the two-pass path for sparse keeps (capi.hip)
+hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t, int num_cus, hipStream_t stream, bool compact = false);
 
 // kept subsets on short records (N <= 4096): output-driven pick through the kept list, no compaction (gt_pick.hip)
 bool gt_pick_applicable(const EmitArgs &a);

@@ -224,6 +224,52 @@ def test_scan_kernels_many_rows_per_wave(per_cu):
             assert (got == exp).all(), f"mask {label} v={v} per_cu={per_cu}"
 
 
+@pytest.mark.parametrize("n,k", [(40_000, 240), (40_000, 241), (40_000, 401), (70_001, 1_915), (70_001, 1_916), (100_003, 4_001), (147_457, 6_002), (147_457, 6_003)])
+def test_two_pass_path_for_sparse_keeps(n, k):
+    """Sparse keeps on long records take TWO passes in AUTO (compact records of K samples, then the all-samples kernels on
+    them): K % 4 in {0,1,2,3} (compact-byte ownership at every segment seam, the ranks behind a slice fetched from later
+    segments), K on both sides of the RUNS / row-item hand-over of the second pass, kept samples clustered at segment
+    ends, chunks of 1, 7 and all rows, a gapped variant list, GT segments and full lines; against the oracle and against the
+    single-pass segment kernel."""
+    rng = np.random.default_rng(n + k)
+    r = oracle.variant_record_size(n)
+    v = 61
+    seam = np.array([s for s in (16383, 16384, 16385, 32767, 32768, 49151, 49152) if s < n])
+    kept = np.unique(np.concatenate([[0, n - 1], seam, rng.choice(n, size=k, replace=False)]))[:k].astype(np.uint32)
+    if kept.size < k:
+        kept = np.unique(np.concatenate([kept, rng.choice(n, size=k, replace=False)]))[:k].astype(np.uint32)
+    assert kept.size == k and k * 170 >= n and k * 22 <= n  # inside the two-pass band
+    v_file = v + 13
+    recs = rng.integers(0, 256, size=v_file * r, dtype=np.uint8)
+    vidx = np.sort(rng.choice(v_file, size=v, replace=False))
+    want = oracle.decode_emit(recs, v, n, kept_idx=kept, variant_idx=vidx).reshape(v, -1)
+    for chunk in (0, 1, 7):
+        tune = {_capi.KNOB_SCAN_CHUNK_ROWS: chunk}
+        for use_vidx in (True, False):
+            w = want if use_vidx else oracle.decode_emit(recs, v, n, kept_idx=kept).reshape(v, -1)
+            got, kk = run_engine(recs, v, n, kept=kept, variant_idx=vidx if use_vidx else None, out_offset=3, tune=tune)
+            exp = expect_buffer(w, v, kk, 4 * kk + 1, 3, got.size)
+            assert (got == exp).all(), f"two-pass chunk={chunk} vidx={use_vidx}"
+    got1, kk = run_engine(recs, v, n, kept=kept, variant_idx=vidx, out_offset=3, tune={_capi.KNOB_SCAN_TWO_PASS: -1})
+    assert (got1 == expect_buffer(want, v, kk, 4 * kk + 1, 3, got1.size)).all(), "single pass"
+    # full lines
+    prefixes = [bytes(rng.integers(33, 127, size=int(rng.integers(0, 40)) if i % 3 else 0, dtype=np.uint8)) for i in range(v)]
+    blob = np.frombuffer(b"".join(prefixes) + b"!", dtype=np.uint8)
+    poff = np.cumsum([0] + [len(q) for q in prefixes]).astype(np.int64)
+    loff = np.cumsum([0] + [len(q) + 4 * k + 1 for q in prefixes]).astype(np.int64)
+    wl = oracle.emit_lines(recs, v, n, blob, poff.astype(np.uint64), loff.astype(np.uint64), kept_idx=kept, variant_idx=vidx)
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        for chunk in (0, 5):
+            eng.tune(_capi.KNOB_SCAN_CHUNK_ROWS, chunk)
+            out = torch.full((2 + int(loff[-1]) + 48,), SENTINEL, dtype=torch.uint8, device=DEV)
+            eng.emit_lines(torch.from_numpy(recs).to(DEV), v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV),
+                           torch.from_numpy(loff).to(DEV), 40, out[2:], variant_idx=torch.tensor(vidx, dtype=torch.int32, device=DEV))
+            eng.wait()
+            got = out.cpu().numpy()
+            assert (got[:2] == SENTINEL).all() and (got[2 + wl.size :] == SENTINEL).all()
+            assert bytes(got[2 : 2 + wl.size]) == wl.tobytes(), f"lines, chunk={chunk}"
+
+
 @pytest.mark.parametrize("n", [16384, 16385, 49152, 49153, 70001, 98304, 100003, 147457])
 def test_sparse_subsets_segment_triples(n):
     """Sparse keeps where the number of 16 384-sample segments is 1..10, i.e. the last block of the
@@ -651,14 +697,15 @@ def test_config3_full_size_100k_by_500k(v):
 
 
 @pytest.mark.parametrize("v", [100_000, 125_000])
-@pytest.mark.parametrize("xcd_map", [1, -1])
-def test_config5_geometry_500k_samples_keep_1pct(xcd_map, v):
+@pytest.mark.parametrize("path", ["two_pass", "segment_xcd", "segment_plain"])
+def test_config5_geometry_500k_samples_keep_1pct(path, v):
     """BASELINE config 5's per-GPU geometry in ONE launch: 100 000 variants x 500 000 samples and the
     125 000-variant shard each of 8 GPUs owns (12.5 / 15.6 GB of records, offsets beyond 2^32), the 1 %
     splitmix keep mask of SURVEY 8(d) (4 940 kept -> 19 761-byte rows, 1.98 / 2.47 GB of text).
-    The segment pick kernel with the XCD-aware and the plain block map: LF / TAB / slash columns over the whole buffer, byte
+    AUTO (two passes: compact records, then the row-item stream kernel on them) and the single-pass segment kernel with the
+    XCD-aware and the plain block map: LF / TAB / slash columns over the whole buffer, byte
     equality with the oracle on rows from the start, the reference's u32-wrap boundary, the middle and
-    the end, and equality of the two launches' whole outputs through a checksum of checksums."""
+    the end, and equality of the three paths' whole outputs through a checksum of checksums."""
     n = 500_000
     free, _total = torch.cuda.mem_get_info(0)
     if free < v * 125_000 + (8 << 30):
@@ -667,9 +714,9 @@ def test_config5_geometry_500k_samples_keep_1pct(xcd_map, v):
     k = int(kept.size)
     row = 4 * k + 1
     with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
-        eng.tune(_capi.KNOB_SCAN_XCD_MAP, xcd_map)
+        eng.tune(_capi.KNOB_SCAN_XCD_MAP, -1 if path == "segment_plain" else 1)
         recs = eng.synth_records(v)
-        out = eng.decode_emit(recs, v, kernel=_capi.KERNEL_SCAN)
+        out = eng.decode_emit(recs, v, kernel=_capi.KERNEL_AUTO if path == "two_pass" else _capi.KERNEL_SCAN)
         eng.wait()
         assert out.numel() == v * row
         assert bool((out[row - 1 :: row] == 10).all())
