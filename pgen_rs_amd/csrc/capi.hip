@@ -72,6 +72,9 @@ int bind(const pgenhip_ctx *ctx)
 // text per row and segment) and the all-samples kernels turn those into text with whole-line stores.  Worth it while the text is
 // small against the records.  Measured band (N = 500 000, profiles/r02_kernel_sweeps.md): 0.5 % kept -2 %, 0.65 % +4 %, 1 % +15 %,
 // 2 % +11 %, 4 % +7 %, 5 % level, 10 % -4 %  ->  0.6 % .. 4.5 % kept.
+// (Short records, N <= 4 096, were tried through the same two passes with a COMPACT instantiation of the short-record pick
+// kernel: 0.42-0.50 of roofline against the single pass's 0.52-0.63 at every density — the compaction costs more than the text
+// it saves there; profiles/r02_kernel_sweeps.md.)
 bool two_pass_shape(uint32_t sample_count, uint32_t kept_count)
 {
     return sample_count > 4096u && kept_count >= 8u && (uint64_t)kept_count * 170ull >= (uint64_t)sample_count &&
@@ -414,11 +417,11 @@ static int claim_counters(pgenhip_ctx *ctx, EmitArgs &a)
     } while (0)
 
 // measured crossover (profiles/r01_kernel_sweeps.md: N = 500 000, 0.2 % kept list gather 1.13 ms vs 1.49 ms,
-// 0.4 % kept 1.51 vs 1.47): below ~1/300 kept on long records the list gather touches only the kept
+// 0.4 % kept 1.51 vs 1.47; round 2, with the faster segment kernel: 0.25 % 1.33 vs 1.51, 0.33 % 1.48 vs 1.52, 0.4 % 1.60 vs 1.57): below ~1/280 kept on long records the list gather touches only the kept
 // samples' lines and wins; everywhere else the segment kernels do (they read each record once, wide)
 static bool very_sparse(const pgenhip_ctx *ctx)
 {
-    return ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 300ull <= ctx->sample_count;
+    return ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 280ull <= ctx->sample_count;
 }
 
 // AUTO for all samples kept, GT segments at a.out + j * a.out_stride
@@ -463,8 +466,9 @@ static int dispatch_all_samples_lines(pgenhip_ctx *ctx, const EmitArgs &a)
 // compacts each row's kept codes into a K-sample record, (2) the all-samples dispatch above turns those records into text.
 static bool two_pass(const pgenhip_ctx *ctx, const EmitArgs &a)
 {
+    // (full lines: only where the second pass is the stream kernel's LINES mode, K >= 1 024 — below that it would flush row by row)
     return ctx->tune.scan_two_pass != 0 && ctx->d_compact != nullptr && a.kept_idx != nullptr && a.record_size >= 16u &&
-           (a.line_off != nullptr || a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull);
+           (a.line_off != nullptr ? a.kept_count >= 1024u : (a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull));
 }
 
 static int dispatch_two_pass(pgenhip_ctx *ctx, const EmitArgs &a, const ScanArgs &sc)
@@ -531,13 +535,13 @@ static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t re
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;  // `--include-sam` that keeps everybody: same bytes, the all-samples kernels
             if (a.kept_idx == nullptr) return dispatch_all_samples(ctx, a);
+            if (two_pass(ctx, a) && !very_sparse(ctx))
+                return dispatch_two_pass(ctx, a, sc);
             if (gt_pick_applicable(a))
                 // short records (the 1000 Genomes shape with a sample filter): output-driven pick, any density
                 LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
             else if (very_sparse(ctx) || ctx->record_size < 16u)
                 LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
-            else if (two_pass(ctx, a))
-                return dispatch_two_pass(ctx, a, sc);
             else
                 LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
@@ -610,12 +614,12 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;
             if (a.kept_idx == nullptr) return dispatch_all_samples_lines(ctx, a);
+            if (two_pass(ctx, a) && !very_sparse(ctx)) return dispatch_two_pass(ctx, a, sc);
             if (gt_pick_applicable(a)) {
                 // kept subset on short records: the pick kernel flushes each parked row behind its prefix
                 LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
                 LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             } else if (ctx->record_size >= 16u && !very_sparse(ctx)) {
-                if (two_pass(ctx, a)) return dispatch_two_pass(ctx, a, sc);
                 // kept subset: the segment kernel writes each GT segment behind its prefix, the prefix kernel the rest
                 LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
                 LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
