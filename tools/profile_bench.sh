@@ -15,4 +15,4 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-delivered "$@" > $OUT/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -5 $OUT/pmc_write.log; exit 1; }
 python3 $ROOT/tools/summarize_profile.py $OUT $OUT/summary
 # keep the merge-back small: the raw traces are large, the summary is what gets committed
-rm -rf $OUT/trace/*/*_kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/trace/*/*_kernel_trace.csv $OUT/pmc_fetch/*/*_kernel_trace.csv $OUT/pmc_write/*/*_kernel_trace.csv

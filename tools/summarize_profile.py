@@ -5,7 +5,7 @@
   bench_under_rocprofv3.json  the bench line printed INSIDE that rocprofv3 process (its roofline.kernel_ms_avg are the
                               same launches as the CSV's average)
   bench.json                  the plain bench line (its own process)
-  pmc_summary.json            FETCH_SIZE / WRITE_SIZE of the dominant GT kernel from the two --pmc passes (KiB), the shape,
+  pmc_summary.json            FETCH_SIZE / WRITE_SIZE per pgenhip_decode_emit call (all its GT kernels) from the two --pmc passes (KiB), the shape,
                               and hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE doubled per
                               MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of 16-B/lane streaming loads at 64 B)
 
@@ -29,19 +29,23 @@ def last_json_line(path):
     return None
 
 
-def counter_mean(root, counter):
+def counter_per_call(root, counter, log_path):
+    """Sum of `counter` over every GT kernel dispatch of the pass (a two-pass path has two kernels per call), divided by the number of
+    pgenhip_decode_emit calls the pass made ((steps + warmup) x launches_per_step, read from the bench line the pass printed)."""
     files = glob.glob(os.path.join(root, "*", "*_counter_collection.csv"))
     per_kernel = {}
     for f in files:
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "pgenhip" in r["Kernel_Name"] and "synth" not in r["Kernel_Name"] and "copy_prefixes" not in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and "pgenhip" in r["Kernel_Name"] and "synth" not in r["Kernel_Name"]:
                 m = re.match(r"^(.*?_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
                 per_kernel.setdefault(m.group(1) if m else r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-    if not per_kernel:
-        return None, None
-    name = max(per_kernel, key=lambda k: sum(per_kernel[k]))
-    vals = per_kernel[name]
-    return name, {"launches": len(vals), "mean_KiB": sum(vals) / len(vals), "min_KiB": min(vals), "max_KiB": max(vals)}
+    line = last_json_line(log_path)
+    if not per_kernel or not line:
+        return None
+    calls = (line["steps"] + line["warmup"]) * line["config"]["launches_per_step"]
+    total = sum(sum(v) for v in per_kernel.values())
+    return {"calls": calls, "KiB_per_call": total / calls,
+            "kernels": {k: {"dispatches": len(v), "KiB_per_call": sum(v) / calls} for k, v in per_kernel.items()}}
 
 
 def main():
@@ -56,12 +60,12 @@ def main():
     for name, obj in (("bench.json", plain), ("bench_under_rocprofv3.json", under)):
         if obj is not None:
             json.dump(obj, open(os.path.join(dst, name), "w"), indent=1)
-    kf, fetch = counter_mean(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
-    kw, write = counter_mean(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    fetch = counter_per_call(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", os.path.join(src, "pmc_fetch.log"))
+    write = counter_per_call(os.path.join(src, "pmc_write"), "WRITE_SIZE", os.path.join(src, "pmc_write.log"))
     ref = plain or under or {}
     cfg, roof = ref.get("config", {}), ref.get("roofline", {})
     summary = {
-        "kernel": kf or kw,
+        "kernels": sorted(set((fetch or {}).get("kernels", {})) | set((write or {}).get("kernels", {}))),
         "shape": {"variants_per_launch": cfg.get("variants_per_launch"), "samples": cfg.get("samples"), "kept": cfg.get("kept_samples"),
                   "preset": cfg.get("preset"), "distribution": cfg.get("distribution")},
         "FETCH_SIZE": fetch,
@@ -69,12 +73,12 @@ def main():
         "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch"),
     }
     if fetch and write:
-        hbm = int((2.0 * fetch["mean_KiB"] + write["mean_KiB"]) * 1024)
+        hbm = int((2.0 * fetch["KiB_per_call"] + write["KiB_per_call"]) * 1024)
         summary["hbm_bytes_per_launch"] = hbm
         if roof.get("algorithmic_bytes_per_launch"):
             summary["traffic_over_algorithmic"] = hbm / roof["algorithmic_bytes_per_launch"]
-        summary["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md "
-                           "(gfx950 counts the 128-B requests of 16-B/lane streaming loads as 64 B)")
+        summary["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, summed over every GT kernel of one pgenhip_decode_emit call; "
+                           "units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts the 128-B requests of 16-B/lane streaming loads as 64 B)")
     json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     print(json.dumps(summary))
     if stats:
