@@ -1,24 +1,20 @@
-// gt_wide.hip — dense all-samples kernel with wide, LDS-staged record loads (gfx950 / MI355X).
+// gt_wide.hip — the work-queue STREAM kernel: all samples kept, dense text, wide LDS-staged record loads (gfx950 / MI355X).
 //
-// Same contract and output-stream view as gt_flat.hip (K = N, rows packed at 4N+1 bytes; every
-// lane stores one 16-byte-ALIGNED chunk of the launch's output stream), but the 2-bit words are
-// no longer fetched with two byte loads per chunk.  Measured on MI355X (tools/membench): a kernel
-// that pairs each 1-KiB wave store with a 64-byte wave load tops out at ~4.3 TB/s whatever the
-// pipelining depth, while one 1-KiB wide load feeding sixteen 1-KiB stores reaches ~5.3 TB/s —
+// Same contract and output-stream view as gt_flat.hip (K = N, rows packed at 4N+1 bytes; every lane stores one
+// 16-byte-ALIGNED chunk of the launch's output stream), but the 2-bit words are no longer fetched with two byte loads per
+// chunk.  Measured on MI355X (tools/membench): a kernel that pairs each 1-KiB wave store with a 64-byte wave load tops out
+// at ~4.3 TB/s whatever the pipelining depth, while one 1-KiB wide load feeding sixteen 1-KiB stores reaches ~5.3 TB/s —
 // few, large read bursts disturb the HBM write stream far less than many small ones.
 //
-// Work item = (row j, span k): one WAVE owns up to 1024 consecutive chunks (16 KiB of text) that
-// start inside row j.  The wave
-//   1. loads the <= 1026 record bytes behind them with ONE global_load_dwordx4 per lane
-//      (16-B-aligned addresses, 8+ whole 128-B lines per instruction) and parks them in its
-//      private LDS slab (ds_write_b128),
-//   2. then runs 16 store steps: lane reads its 10-bit window (ds_read_u16 at the byte it needs),
-//      expands 5 genotypes to text, funnel-shifts by the row's phase (wave-uniform here) and
-//      issues one global_store_dwordx4 — 1 KiB of contiguous text per wave instruction.
-// The next item's record bytes are requested before the stores of the current one are issued
-// (register double-buffering), so loads stay in flight behind the store stream.
-// The chunk that holds a row's '\n' also holds the head of row j+1: its first bytes come from a
-// direct byte load (one lane per row).  Stream head/tail chunks use masked byte stores.
+// One kernel (gt_stream_dyn_kernel), three kinds of work item:
+//   * ROW ITEMS  (row j, span k): up to 1 024 consecutive chunks (16 KiB of text) that start inside row j — N >= 1 916;
+//   * LINES      the same items with every row's GT segment behind its own prefix (pgenhip_emit_lines, N >= 1 024);
+//   * RUNS       a run of B consecutive SHORT rows as one item (8 <= N <= 1 915, dense records): one wide load for the
+//                run's contiguous records, the text staged through LDS in 4-KiB groups so that the row-crossing chunks are
+//                built in one pass and every 128-B line leaves whole.
+// Roles inside a 512-thread block: wave 0 only loads (16 B per lane per item -> LDS slab ring), waves 1-7 only store
+// (ds_read_u16 window -> text -> global_store_dwordx4 nt, 1 KiB of contiguous text per wave instruction); items come from a
+// self-cleaning work queue in global memory.  Details at each piece below.
 #include "gt_common.hip.h"
 #include "kernels.h"
 
