@@ -103,6 +103,9 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
 {
     __shared__ uint16_t s_tab[kPadBefore + kMaxSamples + kPadAfter];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
+    // per wave and batch row: 16 zero bytes, then the row's first four genotypes as text (its first 16 bytes) — what the chunk
+    // that holds the PREVIOUS row's '\n' needs behind it
+    __shared__ __attribute__((aligned(16))) uint32_t s_heads[kWaves][(kMaxBatchRows + 1) * 8];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
         for (uint32_t r = tid; r < kPadBefore + K + kPadAfter; r += (uint32_t)kThreads)
             s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? (uint16_t)a.kept_idx[r - kPadBefore] : (uint16_t)0;
     }
+    for (uint32_t r = tid; r < (uint32_t)kWaves * (kMaxBatchRows + 1) * 8u; r += (uint32_t)kThreads) (&s_heads[0][0])[r] = 0u;
     __syncthreads();
     const uint16_t *const s_idx = s_tab + kPadBefore;
 
@@ -191,6 +195,23 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
         const uint32_t n_chunks = (len - head) >> 4;
         const uint32_t tail_off = head + (n_chunks << 4);
         const uint32_t tail = len - tail_off;                   // bytes after the last whole chunk (< 16)
+        // the heads of the batch's rows 1 .. rows_here-1 (lane i: row i), once per batch: the chunk loop below then builds a
+        // row-crossing chunk from ONE 16-byte text of this row, five dwords of the next row's head and a byte merge instead of
+        // a second five-genotype gather (that path runs in every store step on rows of ~1 KB; in-process A/B on the chr22 shape:
+        // 5 % kept 0.514 -> 0.545 of roofline, 10 % 0.512 -> 0.563, 20 % 0.565 -> 0.577, >= 30 % +1 %)
+        uint32_t *const heads = s_heads[wave];
+        if (lane >= 1u && lane < rows_here) {
+            const uint8_t *hrow = stage + lane * p.pitch;
+            v4u ht;
+            ht.x = gt_text(pick_code<IDENT>(hrow, s_idx, 0, K));
+            ht.y = gt_text(pick_code<IDENT>(hrow, s_idx, 1, K));
+            ht.z = gt_text(pick_code<IDENT>(hrow, s_idx, 2, K));
+            ht.w = gt_text(pick_code<IDENT>(hrow, s_idx, 3, K));
+            *reinterpret_cast<v4u *>(heads + lane * 8u + 4u) = ht;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (uint32_t c = lane; c < n_chunks; c += 64u) {
             const uint32_t o = head + (c << 4);
             uint32_t i, pos;
@@ -201,7 +222,16 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
             if (nl < 16u) {
                 // the chunk holds '\n' at byte nl and the head of the next row behind it (a whole chunk never ends the run)
                 u32x4 y = {0u, 0u, 0u, 0u};
-                if (nl < 15u) y = pick_text16<IDENT>(row + p.pitch, s_idx, -(int32_t)nl - 1, K);
+                if (nl < 15u) {
+                    // bytes nl+1 .. 15 of the chunk = bytes 0 .. of row i+1: its head shifted up by sh = nl + 1 bytes (zeros come in below)
+                    const uint32_t sh = nl + 1u, bsh = sh & 3u;
+                    const uint32_t *e = heads + (i + 1u) * 8u + 3u - (sh >> 2);
+                    const uint32_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
+                    y.x = bsh ? funnel_bytes(e0, e1, 4u - bsh) : e1;
+                    y.y = bsh ? funnel_bytes(e1, e2, 4u - bsh) : e2;
+                    y.z = bsh ? funnel_bytes(e2, e3, 4u - bsh) : e3;
+                    y.w = bsh ? funnel_bytes(e3, e4, 4u - bsh) : e4;
+                }
                 uint32_t xs[4] = {v.x, v.y, v.z, v.w};
                 uint32_t ys[4] = {y.x, y.y, y.z, y.w};
                 uint32_t os[4];
