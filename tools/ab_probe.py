@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--arms", nargs="+", default=["auto"])
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=3, help="launches per timing")
+    ap.add_argument("--lines", type=int, default=0, metavar="PREFIX_BYTES",
+                    help="full VCF body lines (pgenhip_emit_lines) with synthetic prefixes of about this many bytes instead of GT segments")
     args = ap.parse_args()
     n, v = args.samples, args.variants
     kept = None
@@ -52,13 +54,31 @@ def main():
         arms.append((spec, KERNELS[name], eng))
     e0 = arms[0][2]
     recs = e0.synth_records(v)
-    out = torch.empty(v * e0.gt_row_bytes, dtype=torch.uint8, device="cuda:0")
-    alg = v * (e0.record_size + e0.gt_row_bytes)
+    lines = None
+    if args.lines:
+        rng = np.random.default_rng(2)
+        plen = rng.integers(max(2, args.lines - 8), args.lines + 9, size=v).astype(np.int64)
+        poff = np.concatenate([[0], np.cumsum(plen)]).astype(np.int64)
+        loff = np.concatenate([[0], np.cumsum(plen + e0.gt_row_bytes)]).astype(np.int64)
+        blob = torch.full((int(poff[-1]) + 1,), 65, dtype=torch.uint8, device="cuda:0")
+        lines = (blob, torch.from_numpy(poff).to("cuda:0"), torch.from_numpy(loff).to("cuda:0"), int(plen.max()))
+        out = torch.empty(int(loff[-1]), dtype=torch.uint8, device="cuda:0")
+        alg = v * e0.record_size + 2 * int(poff[-1]) + v * e0.gt_row_bytes
+    else:
+        out = torch.empty(v * e0.gt_row_bytes, dtype=torch.uint8, device="cuda:0")
+        alg = v * (e0.record_size + e0.gt_row_bytes)
+
+    def launch(eng, kern):
+        if lines is None:
+            eng.decode_emit(recs, v, out=out, kernel=kern)
+        else:
+            eng.emit_lines(recs, v, lines[0], lines[1], lines[2], lines[3], out, kernel=kern)
+
     times = {spec: [] for spec, _, _ in arms}
     ref = None
     for spec, kern, eng in arms:  # warm-up + agreement of the arms (checksum of the whole output)
         try:
-            eng.decode_emit(recs, v, out=out, kernel=kern)
+            launch(eng, kern)
         except pgen_rs_amd.PgenHipError as e:
             print(f"{spec}: n/a ({e})")
             times.pop(spec)
@@ -75,7 +95,7 @@ def main():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(args.reps):
-                eng.decode_emit(recs, v, out=out, kernel=kern)
+                launch(eng, kern)
             b.record()
             torch.cuda.synchronize()
             times[spec].append(a.elapsed_time(b) / args.reps)
