@@ -73,8 +73,19 @@ def test_no_getenv_on_the_launch_path():
         assert "getenv" not in p.read_text(), p
 
 
+def test_null_ctx_is_refused_not_dereferenced():
+    lib = _capi.lib
+    assert lib.pgenhip_tune(None, _capi.KNOB_WIDE_RANGES, 8) == _capi.ERR_BAD_ARG
+    assert lib.pgenhip_set_stream(None, None) == _capi.ERR_BAD_ARG
+    assert lib.pgenhip_wait(None) == _capi.ERR_BAD_ARG
+    assert lib.pgenhip_decode_emit(None, None, 0, None, 0, None, 0, 0) == _capi.ERR_BAD_ARG
+    assert lib.pgenhip_decode_emit_at(None, None, None, 0, None, 0, 0) == _capi.ERR_BAD_ARG
+    assert lib.pgenhip_destroy(None) == _capi.OK          # like free(NULL)
+    assert lib.pgenhip_kept_count(None) == 0 and lib.pgenhip_gt_row_bytes(None) == 0
+
+
 def test_strerror_covers_all_statuses():
-    for s in range(0, -11, -1):
+    for s in range(0, -13, -1):
         assert _capi.lib.pgenhip_strerror(s) not in (None, b"unknown status")
 
 

@@ -436,6 +436,21 @@ def test_hip_graph_capture_and_replay(n, kept_frac):
         eng.use_torch_stream()
 
 
+def test_tune_rejects_unknown_knobs_and_values():
+    with pgen_rs_amd.GtEngine(2504, device=0) as eng:
+        for knob, value in ((99, 1), (_capi.KNOB_WIDE_RANGES, 3), (0, 0)):
+            with pytest.raises(pgen_rs_amd.PgenHipError) as ei:
+                eng.tune(knob, value)
+            assert ei.value.status == _capi.ERR_BAD_ARG
+        for knob in (_capi.KNOB_WIDE_BLOCKS_PER_CU, _capi.KNOB_WIDE_RANGES, _capi.KNOB_FLAT_BLOCKS_PER_CU, _capi.KNOB_SCAN_BLOCKS_PER_CU,
+                     _capi.KNOB_PICK_BATCH_BYTES, _capi.KNOB_RUNS_ROWS, _capi.KNOB_SCAN_CHUNK_ROWS):
+            eng.tune(knob, 0)   # 0 = back to the built-in default
+        recs = eng.synth_records(50)
+        out = eng.decode_emit(recs, 50)
+        eng.wait()
+        assert out.cpu().numpy().tobytes() == oracle.decode_emit(recs.cpu().numpy(), 50, 2504).tobytes()
+
+
 def test_single_variant_and_zero_variants():
     n = 90
     recs = np.arange(oracle.variant_record_size(n), dtype=np.uint8)
