@@ -15,6 +15,8 @@
 // Roles inside a 512-thread block: wave 0 only loads (16 B per lane per item -> LDS slab ring), waves 1-7 only store
 // (ds_read_u16 window -> text -> global_store_dwordx4 nt, 1 KiB of contiguous text per wave instruction); items come from a
 // self-cleaning work queue in global memory.  Details at each piece below.
+#include <algorithm>
+
 #include "gt_common.hip.h"
 #include "kernels.h"
 
@@ -688,6 +690,346 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
 
 
 // ---------------------------------------------------------------------------------------------
+// gt_lineruns_kernel — FULL LINES (pgenhip_emit_lines, src/pfile.rs:156-192) on SHORT rows, all samples kept, dense records:
+// the RUNS idea for whole VCF body lines.  Lines are packed back to back, so a run of B lines is ONE contiguous piece of the
+// output: prefix_0 GT_0 '\n' prefix_1 GT_1 '\n' ...  A work item is such a run; the loader hands a storer the run's records
+// (one wide load of the contiguous record bytes), its prefix bytes (one wide load of the contiguous piece of the prefix blob) and
+// the lines' start and prefix offsets relative to the run.  The storer emits the run in 4-KiB groups through its LDS stage:
+//   A. lane <-> 16-byte-aligned chunk: chunks that lie wholly inside one line's GT text are built as in the RUNS mode (the line is
+//      found by comparing with the few line starts of the group);
+//   B. everything else — the last bytes of a line's GT text, its '\n', the next line's prefix, the first bytes of that line's GT
+//      text up to the next chunk boundary — is written into the stage byte by byte, one wave pass per line of the group (all
+//      bounds wave-uniform);
+//   C. four 1-KiB stores of whole 128-B lines.
+// Against flushing row by row behind a separate prefix copy (gt_pick.hip LINES: 0.24 of roofline at N = 300) every 128-B line
+// leaves whole, once.
+constexpr uint32_t kLrMaxRows = 30;                       // lines per item (+ the line behind the run)
+constexpr uint32_t kLrRecBytes = kSlabBytes;              // slab: [records | prefix bytes | lrel[32] | prel[32]]
+constexpr uint32_t kLrPfxBytes = 768;
+constexpr uint32_t kLrSlab = kLrRecBytes + kLrPfxBytes + 2u * 32u * 4u;
+
+// one text byte of GT-segment offset x of the record at slab offset rec_off (src/pfile.rs:171-187)
+__device__ __forceinline__ uint32_t run_text_byte(const uint8_t *slab, uint32_t rec_off, uint32_t x)
+{
+    const uint32_t code = ((uint32_t)slab[rec_off + (x >> 4)] >> (((x >> 2) & 3u) * 2u)) & 3u;
+    return gt_text_byte(code, x & 3u);
+}
+
+__device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WideParams &p, const Item &it, const uint8_t *slab, uint8_t *stage,
+                                               uint32_t pdelta, uint32_t lane)
+{
+    const int32_t N4 = (int32_t)(4u * a.sample_count);              // GT text bytes of a line, without its '\n'
+    const uint32_t R = a.record_size;
+    const uint32_t delta = (uint32_t)it.delta;                      // slab offset of the run's first record
+    const uint8_t *const pfx = slab + kLrRecBytes + pdelta;         // line r's prefix bytes at pfx + prel[r]
+    const uint32_t *const lrel = reinterpret_cast<const uint32_t *>(slab + kLrRecBytes + kLrPfxBytes);  // line starts, run-relative
+    const uint32_t *const prel = lrel + 32;                         // prefix starts, relative to the run's first prefix
+    const uint32_t nrows = (uint32_t)min((uint64_t)p.run_rows, (uint64_t)a.n_variants - it.row);
+    const bool has_next = it.row + (uint64_t)nrows < (uint64_t)a.n_variants;
+    const int32_t run_len = (int32_t)lrel[nrows];
+    uint8_t *const chunk0 = a.out - p.head;
+    const int32_t c_first = (int32_t)it.c_first;
+    uint8_t *const span_ptr = chunk0 + (it.g0 - it.lead) * 16ull + lane * 16u;   // lane's chunk in step 0
+    const uint32_t end = it.lead + it.cnt;
+    // the chunk grid is anchored at c_first (mod 16): start of the chunk that holds run offset x / first chunk start >= x
+    auto adown = [&](int32_t x) { return x - ((x - c_first) & 15); };
+    auto aup = [&](int32_t x) { return x + ((c_first - x) & 15); };
+    // only whole chunks inside [0, run_len (+ the line behind the run)) leave as 16-byte stores; the stream's first and last chunk, if
+    // ragged, are written byte-wise from the stage
+    const int32_t own_end = c_first + 16 * (int32_t)it.cnt;         // end of the item's last chunk
+    const bool ragged_head = c_first < 0;
+    const bool ragged_tail = !has_next && own_end > run_len;
+    v4u *const st = reinterpret_cast<v4u *>(stage);
+    // lane l holds line l's start and prefix start (read once per item; wave-uniform values come out with v_readlane, no LDS wait)
+    const int32_t lr_v = lane <= nrows ? (int32_t)lrel[lane] : 0x7FFFFFFF;
+    const uint32_t pr_v = prel[min(lane, 31u)];
+    auto line_start = [&](uint32_t l) { return (int32_t)__builtin_amdgcn_readlane(lr_v, (int)l); };                     // l <= nrows
+    auto line_plen = [&](uint32_t l) { return (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)pr_v, (int)(l + 1u)) - (uint32_t)__builtin_amdgcn_readlane((int)pr_v, (int)l)); };
+    for (uint32_t g = 0; g * 256u < end; g++) {
+        const int32_t gb = c_first + 16 * ((int32_t)(g * 256u) - (int32_t)it.lead);        // run offset of stage byte 0
+        const int32_t glo = max(gb, c_first), ghi = min(gb + 4096, own_end);               // the item's bytes in this group
+        // lines that start inside (glo, ghi): r_lo = last line starting at or before glo
+        uint32_t r_lo = 0u, r_hi = 0u;
+        r_lo = (uint32_t)__popcll(__ballot(lane >= 1u && lr_v <= max(glo, 0)));            // (lanes > nrows hold INT_MAX)
+        r_hi = (uint32_t)__popcll(__ballot(lane >= 1u && lr_v < ghi));
+        // ---- A: every chunk that overlaps the GT text of the line its FIRST byte lies in, as 16 bytes of that line's text at the
+        // chunk's phase (bytes of the chunk outside the GT text are filler: phase B overwrites them)
+        // the group's lines, wave-uniform: start and first GT byte of lines r_lo .. r_lo + 11 (more lines per group only for N < 85)
+        constexpr uint32_t kGroupLines = 12;
+        const uint32_t n_more = min(r_hi, nrows) - min(r_lo, nrows);   // lines after r_lo that start inside the group
+        int32_t l_start[kGroupLines], l_gt[kGroupLines];                // scalars (readfirstlane): a compare against one costs one VALU
+#pragma unroll
+        for (uint32_t q = 0; q < kGroupLines; q++) {
+            l_start[q] = 0x7FFFFFFF;
+            l_gt[q] = 0;
+            if (q <= n_more) {  // wave-uniform
+                const uint32_t l = min(r_lo + q, nrows);
+                l_start[q] = line_start(l);
+                l_gt[q] = l_start[q] + line_plen(l);
+            }
+        }
+        const bool many_lines = r_hi - r_lo >= kGroupLines;
+#pragma unroll
+        for (uint32_t s4 = 0; s4 < 4u; s4++) {
+            if (g * 256u + s4 * 64u >= end) break;
+            const int32_t o = gb + 16 * (int32_t)(s4 * 64u + lane);
+            uint32_t rr = r_lo;
+            int32_t gt_lo = l_gt[0];
+#pragma unroll
+            for (uint32_t q = 1; q < kGroupLines; q++) {
+                if (q <= n_more && l_start[q] <= o) {  // (q <= n_more is wave-uniform: lines the group does not have cost a scalar branch)
+                    rr = r_lo + q;
+                    gt_lo = l_gt[q];
+                }
+            }
+            if (many_lines) {
+                for (uint32_t l = r_lo + kGroupLines; l <= r_hi && l <= nrows; l++) {
+                    const int32_t ls = (int32_t)lrel[l];
+                    if (ls <= o) {
+                        rr = l;
+                        gt_lo = ls + (int32_t)(prel[l + 1u] - prel[l]);
+                    }
+                }
+            }
+            const int32_t x = o - gt_lo;
+            if (x > -16 && x < N4 && rr < nrows) {
+                const uint8_t *const rec = slab + delta + rr * R;
+                uint32_t window;
+                if (x >= 0) {
+                    uint16_t h;
+                    __builtin_memcpy(&h, rec + (x >> 4), 2);
+                    window = h;
+                } else {
+                    window = (uint32_t)rec[0] << 8;  // record byte -1 (none) and byte 0
+                }
+                const u32x4 v = gt_text16_from_window(window, (int64_t)x);
+                st[s4 * 64u + lane] = v4u{v.x, v.y, v.z, v.w};
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- B: what lies between two lines' GT texts, byte by byte on top of A's chunks, one wave pass per line of the group
+        // (all bounds wave-uniform): line l-1's '\n', line l's prefix (lanes 0 .. plen), and — only when that prefix is so short that
+        // the chunk holding line l's first GT byte started back in line l-1 — line l's first GT bytes up to the chunk boundary
+        // (lanes 48 .. 62)
+        for (uint32_t l = r_lo; l <= min(r_hi + 1u, nrows); l++) {
+            const bool line_l = l < nrows || has_next;                        // line l's prefix (and first record byte) is in the slab
+            const int32_t ls = line_start(min(l, nrows));                      // start of line l (= run_len for l == nrows)
+            const int32_t plen = line_l ? line_plen(l) : 0;
+            const int32_t gt_lo = ls + plen;                                   // first GT byte of line l
+            const int32_t lim_hi = min(ghi, l == nrows && !has_next ? run_len : own_end);
+            for (int32_t b = (int32_t)lane; b <= plen; b += 64) {               // b = 0: the '\n' of line l-1, b = 1 .. plen: the prefix
+                const int32_t ob = ls - 1 + b;
+                if ((b >= 1 || l >= 1u) && ob >= glo && ob < lim_hi)
+                    stage[ob - gb] = b == 0 ? (uint8_t)'\n' : pfx[(uint32_t)__builtin_amdgcn_readlane((int)pr_v, (int)min(l, nrows)) + (uint32_t)(b - 1)];
+            }
+            if (line_l && adown(gt_lo) < ls && lane >= 48u) {
+                const int32_t ob = gt_lo + (int32_t)(lane - 48u);
+                if (ob < aup(gt_lo) && ob >= glo && ob < lim_hi) stage[ob - gb] = (uint8_t)run_text_byte(slab, delta + l * R, lane - 48u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- C: four 1-KiB stores
+#pragma unroll
+        for (uint32_t s4 = 0; s4 < 4u; s4++) {
+            const uint32_t u = g * 4u + s4;
+            if (u * 64u >= end) break;
+            const uint32_t i = u * 64u + lane - it.lead;  // wraps to huge before `lead`
+            const v4u v = st[s4 * 64u + lane];
+            const bool whole = i < it.cnt && !(ragged_head && i == 0u) && !(ragged_tail && i + 1u == it.cnt);
+            if (whole) store_chunk<true>(span_ptr + u * 1024u, u32x4{v.x, v.y, v.z, v.w});
+            else if (i < it.cnt) {
+                // the stream's first / last chunk: only the bytes inside [0, run_len)
+                const int32_t o = c_first + 16 * (int32_t)i;
+                uint8_t *const dst = chunk0 + (it.g0 + i) * 16ull;
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int b = 0; b < 16; b++)
+                    if (o + b >= 0 && o + b < run_len) dst[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+            }
+        }
+        // the stage is rewritten by the next group: this group's reads must have returned first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(64 * (NS + 1)) void gt_lineruns_kernel(EmitArgs a, WideParams p)
+{
+    constexpr int RS = 2, DS = RS + 1;
+    __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][RS][kLrSlab];
+    __shared__ __attribute__((aligned(16))) uint8_t s_desc[NS][DS][kDescBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[NS][kStageBytes];
+    __shared__ uint32_t s_full[NS][RS];
+    __shared__ uint32_t s_done[NS][RS];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < NS * RS) {
+        (&s_full[0][0])[threadIdx.x] = 0u;
+        (&s_done[0][0])[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    constexpr uint64_t kNoItem = ~0ull;
+
+    if (wave == 0u) {
+        // ------------------------------ loader wave ------------------------------
+        const uint32_t nr = p.n_ranges;
+        const uint64_t per_range = (p.n_items + (uint64_t)nr - 1ull) / (uint64_t)nr;
+        uint32_t range = blockIdx.x & (nr - 1u);
+        uint32_t drained = 0u;
+        auto issue_claim = [&](uint32_t rng) -> uint64_t {
+            uint64_t got = 0;
+            if (lane == 0u) got = atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counters + rng * 16u), (unsigned long long)NS);
+            return got;
+        };
+        const uint32_t R = a.record_size, B = p.run_rows;
+        uint64_t pending = issue_claim(range);
+        for (uint32_t step = 0;; step++) {
+            uint64_t t0 = kNoItem;
+            uint64_t got = sgpr64(pending);
+            while (drained < nr) {
+                const uint64_t lo = (uint64_t)range * per_range;
+                const uint64_t hi = min(lo + per_range, p.n_items);
+                if (lo + got < hi) {
+                    t0 = lo + got;
+                    break;
+                }
+                range = (range + 1u) & (nr - 1u);
+                drained++;
+                if (drained < nr) got = sgpr64(issue_claim(range));
+            }
+            const uint64_t t_end = t0 == kNoItem ? 0ull : min(t0 + NS, min(((uint64_t)range + 1ull) * per_range, p.n_items));
+            const uint32_t n_here = t0 == kNoItem ? 0u : (uint32_t)(t_end - t0);
+            const uint32_t slot = step % RS;
+            // ---- round trip 1: every item's line / prefix offsets (lane l: row row0 + l, rows row0 .. row0 + nrows + 1) and records
+            uint64_t lo_v[NS], po_v[NS];
+            v4u in0[NS];
+            v4u ext = v4u{0u, 0u, 0u, 0u};
+            const uint8_t *ext_addr = a.records;
+            bool ext_on = false;
+#pragma unroll
+            for (int w = 0; w < NS; w++) {
+                lo_v[w] = 0ull;
+                po_v[w] = 0ull;
+                in0[w] = v4u{0u, 0u, 0u, 0u};
+                if ((uint32_t)w < n_here) {
+                    const uint64_t row0 = (t0 + (uint64_t)w) * (uint64_t)B;
+                    const uint64_t jr = min(row0 + (uint64_t)lane, (uint64_t)a.n_variants);  // both arrays have n_variants + 1 entries
+                    lo_v[w] = a.line_off[jr];
+                    po_v[w] = a.prefix_off[jr];
+                    const uint32_t nrows = (uint32_t)min((uint64_t)B, (uint64_t)a.n_variants - row0);
+                    const uint8_t *const rec = a.records + row0 * (uint64_t)R;
+                    const uint32_t n_bytes = nrows * R + (row0 + nrows < (uint64_t)a.n_variants ? 1u : 0u);
+                    const uint32_t mis = (uint32_t)((uint64_t)(uintptr_t)rec & 15ull);
+                    const uint32_t n_load = (mis + n_bytes + 15u) / 16u;   // <= 66
+                    if (lane < n_load) in0[w] = *reinterpret_cast<const v4u *>(rec - mis + lane * 16u);
+                    if ((lane >> 1) == (uint32_t)w) {
+                        ext_addr = rec - mis + (64u + (lane & 1u)) * 16u;
+                        ext_on = 64u + (lane & 1u) < n_load;
+                    }
+                }
+            }
+            if (ext_on) ext = *reinterpret_cast<const v4u *>(ext_addr);
+            if (t0 != kNoItem) pending = issue_claim(range);
+            // ---- round trip 2: the prefix bytes of every item (their place in the blob is known now) + item geometry
+            v4u pin[NS];
+            uint32_t pmis_w[NS];
+#pragma unroll
+            for (int w = 0; w < NS; w++) {
+                pin[w] = v4u{0u, 0u, 0u, 0u};
+                pmis_w[w] = 0u;
+                if ((uint32_t)w >= n_here) {
+                    if (lane == 0u) desc_put_item(s_desc[w][step % DS], Item{}, t0 == kNoItem ? kNoItem - 1ull : kNoItem);
+                    continue;
+                }
+                const uint64_t row0 = (t0 + (uint64_t)w) * (uint64_t)B;
+                const uint32_t nrows = (uint32_t)min((uint64_t)B, (uint64_t)a.n_variants - row0);
+                const bool has_next = row0 + nrows < (uint64_t)a.n_variants;
+                const uint64_t run_start = sgpr64((uint64_t)__shfl((unsigned long long)lo_v[w], 0, 64));
+                const uint64_t run_end = sgpr64((uint64_t)__shfl((unsigned long long)lo_v[w], (int)nrows, 64));
+                const uint64_t p_start = sgpr64((uint64_t)__shfl((unsigned long long)po_v[w], 0, 64));
+                const uint64_t p_end = sgpr64((uint64_t)__shfl((unsigned long long)po_v[w], (int)(nrows + (has_next ? 1u : 0u)), 64));
+                Item it;
+                const uint64_t g_first = (run_start + p.head) >> 4;   // every run owns the chunk that holds its first byte ... see below
+                const uint64_t g_own = (t0 + (uint64_t)w) == 0ull ? g_first : (run_start + p.head + 15ull) >> 4;
+                const uint64_t g_end = (run_end + p.head + 15ull) >> 4;
+                it.row = row0;
+                it.g0 = g_own;
+                it.cnt = (uint32_t)(g_end - g_own);
+                it.lead = (uint32_t)g_own & 63u;
+                it.c_first = (int64_t)(int32_t)((uint32_t)g_own * 16u - p.head - (uint32_t)run_start);
+                it.delta = (int32_t)((uint32_t)((uint64_t)(uintptr_t)(a.records + row0 * (uint64_t)R) & 15ull));
+                it.rec = nullptr;
+                it.base = nullptr;
+                it.n_load = 0u;
+                it.row_tail = false;
+                const uint8_t *const pb = a.prefix_blob + p_start;
+                const uint32_t pmis = (uint32_t)((uint64_t)(uintptr_t)pb & 15ull);
+                const uint32_t p_pieces = (pmis + (uint32_t)(p_end - p_start) + 15u) / 16u;   // <= kLrPfxBytes / 16
+                if (lane < p_pieces) pin[w] = *reinterpret_cast<const v4u *>(pb - pmis + lane * 16u);
+                pmis_w[w] = pmis;
+                if (lane == 0u) {
+                    uint8_t *d = s_desc[w][step % DS];
+                    desc_put_item(d, it, t0 + (uint64_t)w);
+                    *reinterpret_cast<uint32_t *>(d + 52) = pmis;
+                }
+            }
+            // ---- park
+#pragma unroll
+            for (int w = 0; w < NS; w++) {
+                if (step >= (uint32_t)RS) {
+                    const uint32_t want = step - (uint32_t)RS + 1u;
+                    while (lds_flag_read(lds_offset(&s_done[w][slot])) != want) __builtin_amdgcn_s_sleep(1);
+                }
+                if ((uint32_t)w < n_here) {
+                    uint8_t *slab = slabs[w][slot];
+                    *reinterpret_cast<v4u *>(slab + lane * 16u) = in0[w];
+                    if ((lane >> 1) == (uint32_t)w) *reinterpret_cast<v4u *>(slab + (64u + (lane & 1u)) * 16u) = ext;
+                    if (lane < kLrPfxBytes / 16u) *reinterpret_cast<v4u *>(slab + kLrRecBytes + lane * 16u) = pin[w];
+                    if (lane < 32u) {
+                        const uint64_t l0 = (uint64_t)__shfl((unsigned long long)lo_v[w], 0, 64), p0 = (uint64_t)__shfl((unsigned long long)po_v[w], 0, 64);
+                        uint32_t *offs = reinterpret_cast<uint32_t *>(slab + kLrRecBytes + kLrPfxBytes);
+                        offs[lane] = (uint32_t)(lo_v[w] - l0);
+                        offs[32u + lane] = (uint32_t)(po_v[w] - p0);
+                    }
+                }
+                if (lane == 0u) lds_flag_write(lds_offset(&s_full[w][slot]), step + 1u);
+            }
+            if (t0 == kNoItem) break;
+        }
+        if (lane == 0u) {
+            unsigned long long *const exits = reinterpret_cast<unsigned long long *>(a.work_counters + 8u * 16u);
+            if (atomicAdd(exits, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+#pragma unroll
+                for (uint32_t h = 0; h < 8u; h++) atomicExch(reinterpret_cast<unsigned long long *>(a.work_counters + h * 16u), 0ull);
+                atomicExch(exits, 0ull);
+            }
+        }
+    } else {
+        // ------------------------------ storer waves -----------------------------
+        const uint32_t w = wave - 1u;
+        for (uint32_t step = 0;; step++) {
+            const uint32_t slot = step % RS;
+            while (lds_flag_read(lds_offset(&s_full[w][slot])) != step + 1u) __builtin_amdgcn_s_sleep(1);
+            const uint8_t *slab = slabs[w][slot];
+            const uint8_t *desc = s_desc[w][step % DS];
+            uint64_t t = *reinterpret_cast<const uint64_t *>(desc + 8u);
+            t = sgpr64(t);
+            if (t == kNoItem - 1ull) break;
+            if (t != kNoItem) {
+                const Item it = desc_get_item(desc);
+                const uint32_t pdelta = sgpr32(*reinterpret_cast<const uint32_t *>(desc + 52));
+                emit_lines_run(a, p, it, slab, s_stage[w], pdelta, lane);
+            }
+            if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), step + 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // copy_prefixes_kernel — LINES mode: line j's prefix bytes (pvar fields + "GT", src/pfile.rs:157-161)
 // from the blob to out + line_off[j].  1-2 % of the output bytes; a quarter wave per line so four
 // lines are in flight per wave, byte granular because the neighbouring GT bytes belong to the stream
@@ -814,6 +1156,50 @@ hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     void (*dk)(EmitArgs, WideParams) = gt_stream_dyn_kernel<7, false, true, false, 2, true>;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (t.wide_blocks_per_cu > 0) per_cu = t.wide_blocks_per_cu;
+    const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
+    hipLaunchKernelGGL(dk, dim3((uint32_t)(need < cap ? need : cap)), dim3(512), 0, stream, a, p);
+    return hipGetLastError();
+}
+
+// ---- runs of full LINES: short rows, all samples kept, dense records ---------------------------------------------------------
+static uint32_t lineruns_rows_for(const EmitArgs &a)
+{
+    if (a.record_size == 0u || a.max_line_bytes == 0ull || a.max_line_bytes > 15328ull) return 0u;
+    const uint32_t row_text = 4u * a.kept_count + 1u;
+    const uint32_t max_prefix = (uint32_t)a.max_line_bytes - row_text;
+    uint32_t b = 1040u / a.record_size;                                        // one wide load of the run's records (+ 1 byte)
+    b = std::min<uint32_t>(b, 15328u / (uint32_t)a.max_line_bytes);            // the run's chunks (+ lead) fit one span
+    b = std::min<uint32_t>(b, kLrMaxRows);
+    if (max_prefix) b = std::min<uint32_t>(b, (kLrPfxBytes - 16u) / max_prefix - (((kLrPfxBytes - 16u) / max_prefix) ? 1u : 0u));  // prefixes of B + 1 lines
+    return b;
+}
+
+bool gt_lineruns_applicable(const EmitArgs &a)
+{
+    return a.kept_idx == nullptr && a.line_off != nullptr && a.prefix_off != nullptr && !gathered(a) && a.sample_count >= 8u &&
+           (a.n_variants <= 1 || a.record_stride == a.record_size) && a.work_counters != nullptr && lineruns_rows_for(a) >= 2u;
+}
+
+hipError_t launch_gt_lineruns(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream)
+{
+    if (a.n_variants == 0) return hipSuccess;
+    if (!gt_lineruns_applicable(a)) return hipErrorInvalidValue;
+    WideParams p;
+    p.row_bytes = 4ull * a.kept_count + 1ull;
+    p.total_bytes = 0ull;
+    p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 127ull);
+    p.n_ranges = t.wide_ranges == 1 || t.wide_ranges == 4 || t.wide_ranges == 8 ? (uint32_t)t.wide_ranges : 2u;
+    p.spans_per_row = 1u;
+    const uint32_t b_max = lineruns_rows_for(a);
+    p.run_rows = t.runs_rows > 0 && (uint32_t)t.runs_rows < b_max ? (uint32_t)t.runs_rows : b_max;
+    p.run_rec = a.record_size;
+    p.magic = 0u;
+    p.n_items = ((uint64_t)a.n_variants + p.run_rows - 1ull) / p.run_rows;
+    const uint64_t need = (p.n_items + 6ull) / 7ull;
+    void (*dk)(EmitArgs, WideParams) = gt_lineruns_kernel<7>;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, 512, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (t.wide_blocks_per_cu > 0) per_cu = t.wide_blocks_per_cu;
     const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
     hipLaunchKernelGGL(dk, dim3((uint32_t)(need < cap ? need : cap)), dim3(512), 0, stream, a, p);

@@ -64,6 +64,10 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
 bool gt_runs_applicable(const EmitArgs &a);
 bool gt_runs_preferred(const EmitArgs &a);  // what AUTO uses
 hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream);
+// Runs of FULL LINES (line_off / prefix_off set) on short rows, all samples kept, dense records: prefixes, GT text and '\n' of a
+// run of lines assembled in the storers' LDS stages and stored as whole 128-B lines (gt_wide.hip, gt_lineruns_kernel).
+bool gt_lineruns_applicable(const EmitArgs &a);
+hipError_t launch_gt_lineruns(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream);
 
 // Kept-subset segment kernels: number of kept samples before each segment of kScanSegmentSamples samples.
 constexpr uint32_t kScanSegmentSamples = 16384u;

@@ -527,6 +527,42 @@ def test_emit_lines_stream_kernel(n, v, kernel):
         assert (got[out_offset + want.size :] == SENTINEL).all()
 
 
+@pytest.mark.parametrize("n", [8, 9, 33, 61, 100, 300, 301, 302, 303, 500, 1000, 1023, 1500, 1900])
+def test_emit_lines_runs_of_lines(n):
+    """Full lines on SHORT rows through the line-run kernel (a run of lines per work item, prefixes + GT text + '\n' assembled
+    in LDS, whole-line stores): prefixes of 0..40 bytes (empty ones too, so GT segments start at every byte phase and seams fall
+    everywhere in a chunk), V = 1, V smaller than a run, many runs per block, forced 2- and 3-line runs, unaligned output and
+    record pointers, a first line that does not start at output byte 0; sentinel bytes around the output."""
+    rng = np.random.default_rng(9100 + n)
+    r = oracle.variant_record_size(n)
+    for v, out_off, rec_off, rows_knob, lead_gap, pmax in ((1, 0, 0, 0, 0, 40), (2, 5, 3, 0, 0, 40), (9, 15, 1, 2, 7, 25), (257, 16, 15, 3, 0, 40),
+                                                             (3001, 127, 7, 0, 0, 12), (7001, 1, 0, 0, 3, 40)):
+        recs = rng.integers(0, 256, size=rec_off + v * r, dtype=np.uint8)
+        prefixes = [bytes(rng.integers(33, 127, size=int(rng.integers(0, pmax + 1)) if i % 5 else 0, dtype=np.uint8)) for i in range(v)]
+        blob = np.frombuffer(b"?" * 3 + b"".join(prefixes) + b"!", dtype=np.uint8)      # the blob does not start at a prefix either
+        poff = (3 + np.cumsum([0] + [len(q) for q in prefixes])).astype(np.int64)
+        loff = (lead_gap + np.cumsum([0] + [len(q) + 4 * n + 1 for q in prefixes])).astype(np.int64)
+        want = oracle.emit_lines(recs[rec_off:], v, n, blob, poff.astype(np.uint64), (loff - lead_gap).astype(np.uint64))
+        with pgen_rs_amd.GtEngine(n, device=0) as eng:
+            eng.tune(_capi.KNOB_RUNS_ROWS, rows_knob)
+            if v > 5000:
+                eng.tune(_capi.KNOB_WIDE_BLOCKS_PER_CU, 1)
+            out = torch.full((out_off + int(loff[-1]) + 48,), SENTINEL, dtype=torch.uint8, device=DEV)
+            try:
+                eng.emit_lines(torch.from_numpy(recs).to(DEV), v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV),
+                               torch.from_numpy(loff).to(DEV), pmax, out[out_off:], kernel=_capi.KERNEL_RUNS, records_offset=rec_off)
+            except pgen_rs_amd.PgenHipError:
+                assert n > 1900 or 4 * n + 1 + pmax > 7664, "line-run kernel refused a shape it should take"
+                continue
+            eng.wait()
+            got = out.cpu().numpy()
+        body = got[out_off + lead_gap : out_off + lead_gap + want.size]
+        if bytes(body) != want.tobytes():
+            bad = np.flatnonzero(body != want)
+            raise AssertionError(f"n={n} v={v} out_off={out_off} rec_off={rec_off} rows={rows_knob} gap={lead_gap}: {bad.size} bytes differ, first at {bad[:8]}")
+        assert (got[: out_off + lead_gap] == SENTINEL).all() and (got[out_off + lead_gap + want.size :] == SENTINEL).all()
+
+
 @pytest.mark.parametrize("n,frac", [(2504, 0.01), (2504, 0.5), (40000, 0.01), (40000, 0.3), (40000, 0.9), (120000, 0.004), (120000, 0.02)])
 @pytest.mark.parametrize("kernel", [_capi.KERNEL_AUTO, _capi.KERNEL_SCAN, _capi.KERNEL_ROWS, _capi.KERNEL_PICK])
 def test_emit_lines_kept_subsets(n, frac, kernel):
