@@ -713,6 +713,39 @@ def test_wide_kernel_variants(ranges, per_cu):
     assert (got == expect_buffer(want, len(vidx), n, 4 * n + 1, 0, got.size)).all()
 
 
+def test_wide_kernel_every_phase_of_the_row_seam():
+    """Row items of the stream kernel: the seam between two rows (last chunk of row j with its '\\n' and the head of row j+1, first
+    store step of row j+1 starting mid-KiB) at every phase.  N = 1 024 (S = 4 097: the row start moves one byte per row, so 301
+    rows see every phase of a 128-B line and of a chunk), rows whose '\\n' is the last byte of a chunk, several spans per row,
+    every alignment class of the output pointer, gathered and padded records (the first byte of row j+1 comes from wherever
+    that row's record lies), V = 1 and 2."""
+    rng = np.random.default_rng(8100)
+    tune = {_capi.KNOB_WIDE_BLOCKS_PER_CU: 1}
+    for n, v, off in [(1024, 301, 0), (1024, 140, 127), (1055, 97, 1), (2504, 260, 16), (2504, 2, 113), (2527, 33, 15), (4099, 1, 64),
+                      (16415, 21, 0), (40001, 9, 3), (70001, 5, 120)]:
+        r = oracle.variant_record_size(n)
+        recs = rng.integers(0, 256, size=v * r, dtype=np.uint8)
+        want = oracle.decode_emit(recs, v, n).reshape(v, -1)
+        got, _ = run_engine(recs, v, n, kernel=_capi.KERNEL_WIDE, out_offset=off, tune=tune)
+        exp = expect_buffer(want, v, n, 4 * n + 1, off, got.size)
+        if not (got == exp).all():
+            bad = np.flatnonzero(got != exp)
+            raise AssertionError(f"n={n} v={v} off={off}: {bad.size} bytes differ, first at {bad[:8]}")
+    # gathered rows (variant list with repeats and back-steps) and padded records at an odd base address
+    n = 3000
+    r = oracle.variant_record_size(n)
+    for rstride, rec_off in ((r, 0), (r + 5, 3)):
+        v_file = 40
+        recs = rng.integers(0, 256, size=rec_off + v_file * rstride, dtype=np.uint8)
+        vidx = np.array([5, 0, 3, 3, 39, 38, 1, 2, 2, 17] * 7, dtype=np.uint32)
+        dense = np.concatenate([recs[rec_off + i * rstride : rec_off + i * rstride + r] for i in range(v_file)])
+        want = oracle.decode_emit(dense, len(vidx), n, variant_idx=vidx).reshape(len(vidx), -1)
+        for off in (0, 77):
+            got, _ = run_engine(recs, len(vidx), n, kernel=_capi.KERNEL_WIDE, variant_idx=vidx, record_stride=rstride, records_offset=rec_off,
+                                out_offset=off, tune=tune)
+            assert (got == expect_buffer(want, len(vidx), n, 4 * n + 1, off, got.size)).all(), f"gathered stride={rstride} off={off}"
+
+
 @pytest.mark.parametrize("v", [100_000, 125_000])
 def test_config3_full_size_100k_by_500k(v):
     """BASELINE config 3 at its full size in ONE launch: 100 000 variants x 500 000 samples,
