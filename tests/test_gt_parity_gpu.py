@@ -837,3 +837,78 @@ def test_wide_kernel_many_steps_ring_reuse(ranges):
         got = out.cpu().numpy()
         host = recs.cpu().numpy()
     assert got.tobytes() == oracle.decode_emit(host, v, n).tobytes()
+
+
+def _random_case(rng):
+    """One random call of the path: shape, keep list, gather, strides, pointer phases, GT segments or full lines."""
+    # sample counts clustered around the dispatch thresholds of capi.hip (8, 400, 768, 1024, 1400, 1916, 4096, 65536) and spread between
+    edges = [1, 2, 7, 8, 9, 64, 399, 400, 401, 767, 768, 769, 1023, 1024, 1025, 1399, 1400, 1401, 1915, 1916, 1917, 2504, 4095, 4096, 4097, 20011, 65535, 65536, 65537]
+    n = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 30_000))
+    budget = int(rng.choice([300_000, 1_500_000, 6_000_000]))   # genotypes scanned per case: keeps the oracle in milliseconds
+    v = int(min(max(1, budget // n), rng.choice([1, 2, 3, 17, 64, 257, 1031, 5003, 20011])))
+    mode = rng.choice(["all", "all", "dense", "sparse", "tiny", "modulus"])
+    if mode == "all" or n < 2:
+        kept = None
+    elif mode == "dense":
+        kept = np.sort(rng.choice(n, size=max(1, int(n * rng.uniform(0.2, 0.98))), replace=False))
+    elif mode == "sparse":
+        kept = np.sort(rng.choice(n, size=max(1, int(n * rng.uniform(0.002, 0.06))), replace=False))
+    elif mode == "tiny":
+        kept = np.sort(rng.choice(n, size=int(rng.integers(1, min(n, 5) + 1)), replace=False))
+    else:
+        kept = np.arange(int(rng.integers(0, 7)), n, int(rng.integers(2, 130)))
+    lines = bool(rng.random() < 0.4)
+    gather = bool(rng.random() < 0.3)
+    pad = int(rng.choice([0, 0, 0, 1, 5, 16])) if not lines or gather else 0
+    return dict(n=n, v=v, kept=None if kept is None or kept.size == 0 else kept.astype(np.uint32), lines=lines, gather=gather, rec_pad=pad,
+                out_off=int(rng.integers(0, 130)), rec_off=int(rng.integers(0, 18)), out_pad=int(rng.choice([0, 0, 0, 3, 16])) if not lines else 0)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_differential_auto_dispatch(seed):
+    """Seeded random calls through the AUTO dispatch (whatever kernel capi.hip picks for the shape) against the oracle: random N
+    (clustered at every dispatch threshold), V, keep lists (none / dense / sparse / tiny / strided), variant gathers with repeats,
+    padded record and output strides, unaligned record and output pointers, GT segments and full lines with random prefixes.
+    Sentinel bytes everywhere the call must not write.  40 seeds x 40 cases."""
+    rng = np.random.default_rng(77_000 + seed)
+    for case_i in range(40):
+        c = _random_case(rng)
+        n, v, kept = c["n"], c["v"], c["kept"]
+        r = oracle.variant_record_size(n)
+        k = n if kept is None else int(kept.size)
+        rstride = r + c["rec_pad"]
+        v_file = v * 2 if c["gather"] else v
+        recs = rng.integers(0, 256, size=c["rec_off"] + v_file * rstride + 16, dtype=np.uint8)
+        vidx = rng.integers(0, v_file, size=v).astype(np.uint32) if c["gather"] else None
+        dense = np.concatenate([recs[c["rec_off"] + i * rstride : c["rec_off"] + i * rstride + r] for i in range(v_file)]) if r else np.zeros(0, np.uint8)
+        tag = f"seed={seed} case={case_i} {dict((q, (w if not isinstance(w, np.ndarray) else f'K={w.size}')) for q, w in c.items())}"
+        with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+            rec_t = torch.from_numpy(recs).to(DEV)
+            vidx_t = None if vidx is None else torch.tensor(vidx.astype(np.int64), dtype=torch.int32, device=DEV)
+            if c["lines"]:
+                plens = rng.integers(0, 60, size=v)
+                plens[rng.random(v) < 0.2] = 0
+                prefixes = [bytes(rng.integers(33, 127, size=int(q), dtype=np.uint8)) for q in plens]
+                blob = np.frombuffer(b"".join(prefixes) + b"!", dtype=np.uint8)
+                poff = np.cumsum([0] + [len(q) for q in prefixes]).astype(np.int64)
+                loff = np.cumsum([0] + [len(q) + 4 * k + 1 for q in prefixes]).astype(np.int64)
+                want = oracle.emit_lines(dense, v, n, blob, poff.astype(np.uint64), loff.astype(np.uint64), kept_idx=kept, variant_idx=vidx)
+                out = torch.full((c["out_off"] + int(loff[-1]) + 64,), SENTINEL, dtype=torch.uint8, device=DEV)
+                eng.emit_lines(rec_t, v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV), torch.from_numpy(loff).to(DEV),
+                               int(max(plens.max(), 1)), out[c["out_off"]:], record_stride=rstride, variant_idx=vidx_t, records_offset=c["rec_off"])
+                eng.wait()
+                got = out.cpu().numpy()
+                exp = np.full(got.size, SENTINEL, dtype=np.uint8)
+                exp[c["out_off"] : c["out_off"] + want.size] = want
+            else:
+                ostride = 4 * k + 1 + c["out_pad"]
+                want = oracle.decode_emit(dense, v, n, kept_idx=kept, variant_idx=vidx).reshape(v, -1)
+                out = torch.full((c["out_off"] + v * ostride + 64,), SENTINEL, dtype=torch.uint8, device=DEV)
+                eng.decode_emit(rec_t, v, record_stride=rstride, variant_idx=vidx_t, out=out, out_stride=ostride, out_offset=c["out_off"],
+                                records_offset=c["rec_off"])
+                eng.wait()
+                got = out.cpu().numpy()
+                exp = expect_buffer(want, v, k, ostride, c["out_off"], got.size)
+        if not (got == exp).all():
+            bad = np.flatnonzero(got != exp)
+            raise AssertionError(f"{tag}: {bad.size} bytes differ, first at {bad[:8]}")
