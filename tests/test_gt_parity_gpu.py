@@ -527,6 +527,43 @@ def test_emit_lines_stream_kernel(n, v, kernel):
         assert (got[out_offset + want.size :] == SENTINEL).all()
 
 
+@pytest.mark.parametrize("n", [1024, 1025, 1399, 2504, 4099, 16415, 70001])
+def test_emit_lines_long_rows_long_prefixes(n):
+    """Full lines of rows >= 4 KiB through the stream kernel (GT segments in place behind their prefixes + the prefix copy):
+    prefixes from 0 to 700 bytes (empty ones, one-byte ones behind the longest, the 130-250 bytes of the reference's own
+    basic1.pvar rows), V = 1 and 2, a first line that does not start at output byte 0, a blob that does not start at a prefix,
+    unaligned output and record pointers, a gapped variant list, several spans per row; sentinels around the output."""
+    rng = np.random.default_rng(9700 + n)
+    r = oracle.variant_record_size(n)
+    for v, out_off, rec_off, lead_gap, pmax, gather in ((1, 0, 0, 0, 40, False), (2, 5, 3, 0, 480, False), (9, 15, 1, 7, 14, False), (41, 16, 15, 0, 260, True),
+                                                          (130, 127, 7, 3, 480, False), (23, 1, 0, 0, 700, False), (300, 64, 0, 0, 200, True)):
+        v = max(1, min(v, 3_000_000 // n))
+        v_file = v + 5 if gather else v
+        recs = rng.integers(0, 256, size=rec_off + v_file * r, dtype=np.uint8)
+        vidx = np.sort(rng.choice(v_file, size=v, replace=False)) if gather else None
+        plens = [int(rng.integers(0, pmax + 1)) if i % 5 else 0 for i in range(v)]
+        if v > 3:
+            plens[1], plens[2] = pmax, 1                                                  # the longest one, and a one-byte one behind it
+        prefixes = [bytes(rng.integers(33, 127, size=q, dtype=np.uint8)) for q in plens]
+        blob = np.frombuffer(b"?" * 3 + b"".join(prefixes) + b"!", dtype=np.uint8)
+        poff = (3 + np.cumsum([0] + plens)).astype(np.int64)
+        loff = (lead_gap + np.cumsum([0] + [q + 4 * n + 1 for q in plens])).astype(np.int64)
+        want = oracle.emit_lines(recs[rec_off:], v, n, blob, poff.astype(np.uint64), (loff - lead_gap).astype(np.uint64), variant_idx=vidx)
+        with pgen_rs_amd.GtEngine(n, device=0) as eng:
+            eng.tune(_capi.KNOB_WIDE_BLOCKS_PER_CU, 1)
+            out = torch.full((out_off + int(loff[-1]) + 48,), SENTINEL, dtype=torch.uint8, device=DEV)
+            eng.emit_lines(torch.from_numpy(recs).to(DEV), v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV),
+                           torch.from_numpy(loff).to(DEV), max(plens), out[out_off:], kernel=_capi.KERNEL_WIDE, records_offset=rec_off,
+                           variant_idx=None if vidx is None else torch.tensor(vidx, dtype=torch.int32, device=DEV))
+            eng.wait()
+            got = out.cpu().numpy()
+        body = got[out_off + lead_gap : out_off + lead_gap + want.size]
+        if bytes(body) != want.tobytes():
+            bad = np.flatnonzero(body != want)
+            raise AssertionError(f"n={n} v={v} out_off={out_off} rec_off={rec_off} gap={lead_gap} pmax={pmax}: {bad.size} bytes differ, first at {bad[:8]}")
+        assert (got[: out_off + lead_gap] == SENTINEL).all() and (got[out_off + lead_gap + want.size :] == SENTINEL).all(), f"n={n} v={v} wrote outside"
+
+
 @pytest.mark.parametrize("n", [8, 9, 33, 61, 100, 300, 301, 302, 303, 500, 1000, 1023, 1500, 1900])
 def test_emit_lines_runs_of_lines(n):
     """Full lines on SHORT rows through the line-run kernel (a run of lines per work item, prefixes + GT text + '\n' assembled
