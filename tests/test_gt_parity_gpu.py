@@ -949,3 +949,86 @@ def test_randomized_differential_auto_dispatch(seed):
         if not (got == exp).all():
             bad = np.flatnonzero(got != exp)
             raise AssertionError(f"{tag}: {bad.size} bytes differ, first at {bad[:8]}")
+
+
+@pytest.mark.parametrize("n,v,keep_mod", [(300, 4_300_000, 0), (2504, 500_000, 0), (900, 1_350_000, 0), (40_000, 900_000, 29)])
+def test_emit_lines_past_4_gib(n, v, keep_mod):
+    """Full lines whose offsets pass 2^32 in ONE call (5.3 GB of text at the reference's own 300-sample shape through the line-run
+    kernel, 5.0 GB at N = 2 504 through the stream kernel, 4.9 GB at N = 900 through the pick kernel, 5 GB through the two-pass
+    path): every kernel carries run- / row-relative offsets in 32 bits and the place of the run in 64.  Checked against the oracle
+    on windows of lines at the start, around the 4-GiB mark, at the end and at random places; LF at the end of every line
+    and sentinels behind the last one."""
+    free, _ = torch.cuda.mem_get_info()
+    kept = oracle.synth_keep(n, modulus=keep_mod) if keep_mod else None
+    k = n if kept is None else int(kept.size)
+    rng = np.random.default_rng(4400 + n)
+    plen = rng.integers(0, 41, size=v).astype(np.int64)
+    plen[::7] = 0
+    poff = np.concatenate([[0], np.cumsum(plen)]).astype(np.int64)
+    loff = np.concatenate([[0], np.cumsum(plen + 4 * k + 1)]).astype(np.int64)
+    total = int(loff[-1])
+    assert total > (1 << 32) + (1 << 28)
+    if free < total + (3 << 30):
+        pytest.skip("needs the output resident")
+    blob = rng.integers(33, 127, size=int(poff[-1]) + 1, dtype=np.uint8)
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        recs = eng.synth_records(v)
+        out = torch.full((total + 64,), SENTINEL, dtype=torch.uint8, device=DEV)
+        eng.emit_lines(recs, v, torch.from_numpy(blob).to(DEV), torch.from_numpy(poff).to(DEV), torch.from_numpy(loff).to(DEV), 40, out)
+        eng.wait()
+        r = eng.record_size
+        assert (out[total:] == SENTINEL).all().item()
+        ends = torch.from_numpy(loff[1:] - 1).to(DEV)
+        assert (out[ends] == 10).all().item(), "a line does not end in LF"
+        j_4g = int(np.searchsorted(loff, 1 << 32))
+        starts = [0, max(j_4g - 40, 0), v - 60] + [int(q) for q in rng.integers(0, v - 60, size=6)]
+        for j0 in starts:
+            j1 = min(j0 + 60, v)
+            host_recs = recs[j0 * r : j1 * r].cpu().numpy()
+            want = oracle.emit_lines(host_recs, j1 - j0, n, blob, poff[j0 : j1 + 1].astype(np.uint64), (loff[j0 : j1 + 1] - loff[j0]).astype(np.uint64), kept_idx=kept)
+            got = out[int(loff[j0]) : int(loff[j1])].cpu().numpy()
+            if bytes(got) != want.tobytes():
+                bad = np.flatnonzero(got != want)
+                raise AssertionError(f"n={n} lines {j0}..{j1}: {bad.size} bytes differ, first at {bad[:6]}")
+        del out
+
+
+@pytest.mark.parametrize("n,v,keep_frac,pad", [(300, 4_300_000, 0.0, 0), (1000, 1_250_000, 0.0, 0), (2504, 900_000, 0.5, 0), (2504, 3_000_000, 0.15, 0),
+                                                   (300, 4_000_000, 0.0, 3), (12, 95_000_000, 0.0, 0)])
+def test_gt_segments_past_4_gib(n, v, keep_frac, pad):
+    """GT segments whose byte offsets pass 2^32 in ONE call on SHORT records (the long-record kernels have the 200-GB tests): RUNS mode
+    at the reference's own 300-sample shape (5.2 GB) and at N = 1 000, the pick kernel with half and 15 % of 2 504 samples kept,
+    the flat kernel on padded rows, tiny rows in the RUNS mode (N = 12, 95 M rows).  Windows of rows at the start, around
+    the 4-GiB mark, at the end and at random places against the oracle; LF at the end of every row; sentinels in the padding
+    and behind the last row."""
+    free, _ = torch.cuda.mem_get_info()
+    rng = np.random.default_rng(4500 + n + v % 1000)
+    kept = np.sort(rng.choice(n, size=int(n * keep_frac), replace=False)).astype(np.uint32) if keep_frac else None
+    k = n if kept is None else int(kept.size)
+    row = 4 * k + 1
+    ostride = row + pad
+    total = v * ostride
+    assert total > (1 << 32) + (1 << 27)
+    if free < total + (3 << 30):
+        pytest.skip("needs the output resident")
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        recs = eng.synth_records(v)
+        out = torch.full((total + 64,), SENTINEL, dtype=torch.uint8, device=DEV)
+        eng.decode_emit(recs, v, out=out, out_stride=ostride)
+        eng.wait()
+        r = eng.record_size
+        assert (out[total - pad :] == SENTINEL).all().item()
+        rows2d = out[:total].view(v, ostride)
+        assert (rows2d[:, row - 1] == 10).all().item(), "a row does not end in LF"
+        if pad:
+            assert (rows2d[:, row:] == SENTINEL).all().item(), "padding bytes written"
+        j_4g = (1 << 32) // ostride
+        starts = [0, max(j_4g - 50, 0), v - 100] + [int(q) for q in rng.integers(0, v - 100, size=6)]
+        for j0 in starts:
+            j1 = min(j0 + 100, v)
+            want = oracle.decode_emit(recs[j0 * r : j1 * r].cpu().numpy(), j1 - j0, n, kept_idx=kept).reshape(j1 - j0, row)
+            got = rows2d[j0:j1, :row].cpu().numpy()
+            if not (got == want).all():
+                bad = np.argwhere(got != want)
+                raise AssertionError(f"n={n} k={k} rows {j0}..{j1}: {bad.shape[0]} bytes differ, first at row/col {bad[:4].tolist()}")
+        del out, rows2d
