@@ -293,11 +293,10 @@ static int dispatch_all_samples_lines(pgenhip_ctx *ctx, const EmitArgs &a)
     if (gt_wide_lines_applicable(a)) {
         // rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place behind their prefixes (+ a small prefix copy)
         LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
-    } else if (gt_lineruns_applicable(a) && a.sample_count <= 768u) {
-        // short rows, dense records: runs of whole lines (prefix + GT + '\n') assembled in LDS and stored as whole 128-B lines;
-        // ahead of the row-by-row pick kernel up to N ~ 800 (N = 100 / 300 / 500: 0.26 / 0.38 / 0.41 of roofline against
-        // 0.13 / 0.25 / 0.33; N = 1000: 0.42 against 0.44 — the kernel is bound by its loader's two dependent round trips
-        // per step; profiles/r02_kernel_sweeps.md)
+    } else if (gt_lineruns_applicable(a)) {
+        // short rows, dense records: runs of whole lines (prefix + GT + '\n') assembled in LDS and stored as whole 128-B lines:
+        // 0.30 / 0.44 / 0.49 of roofline at N = 100 / 300 / 1 000 against 0.13 / 0.25 / 0.45 for the row-by-row pick kernel below
+        // (profiles/r02_kernel_sweeps.md)
         LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
     } else if (gt_pick_applicable(a)) {
         // shorter rows: the pick kernel (identity for a table) flushes each parked row behind its prefix

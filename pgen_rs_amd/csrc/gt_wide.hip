@@ -1196,13 +1196,21 @@ hipError_t launch_gt_lineruns(const EmitArgs &a, const Tuning &t, int num_cus, h
     p.run_rec = a.record_size;
     p.magic = 0u;
     p.n_items = ((uint64_t)a.n_variants + p.run_rows - 1ull) / p.run_rows;
-    const uint64_t need = (p.n_items + 6ull) / 7ull;
-    void (*dk)(EmitArgs, WideParams) = gt_lineruns_kernel<7>;
+    // THREE storer waves per loader wave, not the stream kernel's seven: this loader has two dependent round trips and about as many
+    // instructions per item as a storer has per 4-KiB group, so with seven storers it is the wave everybody waits for; and its
+    // per-item registers (offsets, records, prefix pieces) set the kernel's VGPR count (110 with seven items in flight, 63 with
+    // three: six 256-thread blocks per CU).  Storers per loader, fraction of roofline at N = 100 / 300 / 1 000 with 30-byte prefixes:
+    // 1: 0.18 / 0.32 / 0.26, 2: 0.28 / 0.41 / 0.45, 3: 0.30 / 0.44 / 0.49, 4: 0.24 / 0.36 / 0.40, 5: 0.20 / 0.29 / 0.32, 7: 0.26 / 0.38 / 0.43
+    // (profiles/r02_kernel_sweeps.md; the GT-only RUNS mode, one round trip and a lighter loader, stays best with seven)
+    constexpr int kStorers = 3;
+    const uint64_t need = (p.n_items + (uint64_t)kStorers - 1ull) / (uint64_t)kStorers;
+    void (*dk)(EmitArgs, WideParams) = gt_lineruns_kernel<kStorers>;
+    constexpr int threads = 64 * (kStorers + 1);
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, 512, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (t.wide_blocks_per_cu > 0) per_cu = t.wide_blocks_per_cu;
     const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
-    hipLaunchKernelGGL(dk, dim3((uint32_t)(need < cap ? need : cap)), dim3(512), 0, stream, a, p);
+    hipLaunchKernelGGL(dk, dim3((uint32_t)(need < cap ? need : cap)), dim3(threads), 0, stream, a, p);
     return hipGetLastError();
 }
 
