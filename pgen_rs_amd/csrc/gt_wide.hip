@@ -12,6 +12,8 @@
 //   * RUNS       a run of B consecutive SHORT rows as one item (8 <= N <= 1 915, dense records): one wide load for the
 //                run's contiguous records, the text staged through LDS in 4-KiB groups so that the row-crossing chunks are
 //                built in one pass and every 128-B line leaves whole.
+// and its sibling for FULL LINES of short rows (gt_lineruns_kernel, N < 1 024): runs of whole lines — prefixes, GT text, '\n' —
+// assembled in the same kind of LDS stage, one loader wave per three storer waves.
 // Roles inside a 512-thread block: wave 0 only loads (16 B per lane per item -> LDS slab ring), waves 1-7 only store
 // (ds_read_u16 window -> text -> global_store_dwordx4 nt, 1 KiB of contiguous text per wave instruction); items come from a
 // self-cleaning work queue in global memory.  Details at each piece below.
@@ -344,11 +346,10 @@ __device__ __forceinline__ void emit_item(const EmitArgs &a, const WideParams &p
 // first byte of the row behind it — with a single 16-B-per-lane load (B*R <= 1 040), and a storer
 // walks the run's 16-byte-ALIGNED chunks exactly like a long row's: chunk at run offset o lies in
 // row o / S (one multiply-high by a host-computed reciprocal) at row byte o % S; its window is two
-// bytes of the slab.  The chunks that hold a '\n' (one per row) are NOT built in the store steps,
-// where one such lane would drag the whole wave through the merge path every step; they are left
-// out of the step's store (the lane is masked) and written afterwards in one pass with lane r on
-// row r's '\n' chunk: tail of row r, '\n', head of row r+1, all from the slab.  The line such a
-// chunk lives in is completed within microseconds by the same wave, so L2 merges the two writes.
+// bytes of the slab.  The chunks that hold a '\n' (one per row) are not built in the store steps, where one
+// such lane would drag the whole wave through the merge path every step: the text leaves through the storer's
+// 4-KiB LDS stage (emit_run below: plain text of every chunk, one fix-up pass over the group's '\n' chunks,
+// four stores of whole 128-B lines).
 __device__ __forceinline__ Item make_run_item(const EmitArgs &a, const WideParams &p, uint64_t t)
 {
     Item it;
