@@ -33,8 +33,9 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr uint32_t kMaxSamples = 4096;          // R <= 1024: one 16-B piece per lane covers a record
-constexpr uint32_t kStageBytes = 8192;          // per wave: B rows at the padded pitch
-constexpr int kMaxBatchRows = 12;
+constexpr uint32_t kStageBytes = 8192;          // per wave: B rows at the padded pitch (PACKED: the batch's contiguous record bytes)
+constexpr int kMaxBatchRows = 12;               // load instructions per batch (one per row; PACKED: one per KiB of the batch's records)
+constexpr uint32_t kMaxPackedRows = 64;         // PACKED batches: rows (their heads are prepared by lane <-> row)
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
@@ -45,6 +46,9 @@ struct PickParams {
     uint32_t row_bytes;   // S = 4K + 1
     uint32_t magic;       // floor(2^32 / S) + 1: o / S = umulhi(o, magic) for o < 2^20 (checked on the host), fixed up by one compare
     uint32_t n_batches;
+    uint32_t packed;      // 1: dense records, no gather — a batch's B records are ONE contiguous run of B*R bytes, fetched KiB by KiB and
+                          // parked as they lie (pitch = R): short records no longer cost a load instruction and a register quad per
+                          // ROW, and a batch is up to 64 rows instead of 12 (N = 300 with 30 samples kept: 7.7 KB of text per batch, not 1.4)
 };
 
 // run offset -> (row in batch, row byte)
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
     // per wave and batch row: 16 zero bytes, then the row's first four genotypes as text (its first 16 bytes) — what the chunk
     // that holds the PREVIOUS row's '\n' needs behind it
-    __shared__ __attribute__((aligned(16))) uint32_t s_heads[kWaves][(kMaxBatchRows + 1) * 8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_heads[kWaves][(kMaxPackedRows + 1) * 8];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
         for (uint32_t r = tid; r < kPadBefore + K + kPadAfter; r += (uint32_t)kThreads)
             s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? (uint16_t)a.kept_idx[r - kPadBefore] : (uint16_t)0;
     }
-    for (uint32_t r = tid; r < (uint32_t)kWaves * (kMaxBatchRows + 1) * 8u; r += (uint32_t)kThreads) (&s_heads[0][0])[r] = 0u;
+    for (uint32_t r = tid; r < (uint32_t)kWaves * (kMaxPackedRows + 1) * 8u; r += (uint32_t)kThreads) (&s_heads[0][0])[r] = 0u;
     __syncthreads();
     const uint16_t *const s_idx = s_tab + kPadBefore;
 
@@ -132,8 +136,22 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
     if (bi >= p.n_batches) return;
 
     v4u buf[kMaxBatchRows];
+    const bool packed = p.packed != 0u;
     auto load_batch = [&](uint32_t b) {
         const uint64_t row0 = (uint64_t)b * B;
+        if (packed) {
+            // the batch's records as one byte run, from the 16-B boundary below its first byte
+            const uint8_t *__restrict__ run0 = a.records + row0 * (uint64_t)R;
+            const uint32_t mis = (uint32_t)(uintptr_t)run0 & 15u;
+            const uint32_t n_bytes = mis + (uint32_t)min((uint64_t)B, (uint64_t)a.n_variants - row0) * R;   // <= kStageBytes (host)
+#pragma unroll
+            for (int i = 0; i < kMaxBatchRows; i++) {
+                buf[i] = v4u{0u, 0u, 0u, 0u};
+                const uint32_t off = (uint32_t)i * 1024u + lane * 16u;
+                if ((uint32_t)i * 1024u < n_bytes && off < n_bytes) buf[i] = *reinterpret_cast<const v4u *>(run0 - mis + off);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < kMaxBatchRows; i++) {
             buf[i] = v4u{0u, 0u, 0u, 0u};
@@ -149,9 +167,19 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
     for (;;) {
         // ---- park this batch's rows (waits for their loads — and, gfx9 having one in-order vmcnt, for the
         // previous batch's stores: one drain per batch of ~32 KiB of text or 12 rows)
+        const uint64_t row0 = (uint64_t)bi * B;
+        const uint32_t rows_here = (uint32_t)min((uint64_t)B, (uint64_t)a.n_variants - row0);
+        // staged row i starts at rows0 + i * pitch (PACKED: pitch = R behind the run's misalignment)
+        const uint8_t *const rows0 = stage + (packed ? (uint32_t)(uintptr_t)(a.records + row0 * (uint64_t)R) & 15u : 0u);
+        if (packed) {
+            const uint32_t n_bytes = (uint32_t)(rows0 - stage) + rows_here * R;
+#pragma unroll
+            for (int i = 0; i < kMaxBatchRows; i++)
+                if ((uint32_t)i * 1024u < n_bytes) *reinterpret_cast<v4u *>(stage + (uint32_t)i * 1024u + lane * 16u) = buf[i];
+        }
 #pragma unroll
         for (int i = 0; i < kMaxBatchRows; i++) {
-            if ((uint32_t)i < B && lane < p.pieces) {
+            if (!packed && (uint32_t)i < B && lane < p.pieces) {
                 v4u x = buf[i];
                 if (tail_shift != 0u) {
                     uint64_t lo = (uint64_t)x.x | ((uint64_t)x.y << 32), hi = (uint64_t)x.z | ((uint64_t)x.w << 32);
@@ -170,13 +198,11 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        const uint64_t row0 = (uint64_t)bi * B;
-        const uint32_t rows_here = (uint32_t)min((uint64_t)B, (uint64_t)a.n_variants - row0);
         if (LINES) {
             // ---- full-line mode: the rows' GT segments sit behind their prefixes, so every row is flushed on its own
             // (whole aligned chunks + one byte-store instruction for its two edges; flush_codes, gt_common.hip.h)
             for (uint32_t i = 0; i < rows_here; i++) {
-                const uint8_t *row = stage + i * p.pitch;
+                const uint8_t *row = rows0 + i * p.pitch;
                 const uint16_t *idx = s_idx;
                 flush_codes([row, idx, K](uint32_t r) { return pick_code<IDENT>(row, idx, (int32_t)r, K); }, 0u, row_text(a, row0 + i), 0ull,
                             (uint64_t)S, 0u, K, lane);
@@ -201,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
         // 5 % kept 0.514 -> 0.545 of roofline, 10 % 0.512 -> 0.563, 20 % 0.565 -> 0.577, >= 30 % +1 %)
         uint32_t *const heads = s_heads[wave];
         if (lane >= 1u && lane < rows_here) {
-            const uint8_t *hrow = stage + lane * p.pitch;
+            const uint8_t *hrow = rows0 + lane * p.pitch;
             v4u ht;
             ht.x = gt_text(pick_code<IDENT>(hrow, s_idx, 0, K));
             ht.y = gt_text(pick_code<IDENT>(hrow, s_idx, 1, K));
@@ -216,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
             const uint32_t o = head + (c << 4);
             uint32_t i, pos;
             split_offset(o, p, i, pos);
-            const uint8_t *row = stage + i * p.pitch;
+            const uint8_t *row = rows0 + i * p.pitch;
             u32x4 v = pick_text16<IDENT>(row, s_idx, (int32_t)pos, K);
             const uint32_t nl = S - 1u - pos;                   // chunk byte of this row's '\n' if < 16
             if (nl < 16u) {
@@ -255,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
             if (on) {
                 uint32_t i, pos;
                 split_offset(o, p, i, pos);
-                const uint32_t code = pick_code<IDENT>(stage + i * p.pitch, s_idx, (int32_t)(pos >> 2), K);
+                const uint32_t code = pick_code<IDENT>(rows0 + i * p.pitch, s_idx, (int32_t)(pos >> 2), K);
                 run[o] = (uint8_t)(pos == S - 1u ? 0x0Au : gt_text_byte(code, pos & 3u));
             }
         }
@@ -290,10 +316,18 @@ hipError_t launch_gt_pick(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     const uint32_t batch_bytes = t.pick_batch_bytes > 0 ? (uint32_t)t.pick_batch_bytes : 32768u;
     uint32_t b = (batch_bytes + p.row_bytes - 1u) / p.row_bytes;
     b = b < 1u ? 1u : b;
-    if (b > (uint32_t)kMaxBatchRows) b = (uint32_t)kMaxBatchRows;
-    if (b > kStageBytes / p.pitch) b = kStageBytes / p.pitch;  // >= 8 (pitch <= 1024)
+    // dense records and no gather: the batch's records are one contiguous run (rows at pitch R, up to 64 of them)
+    p.packed = !gathered(a) && (a.n_variants <= 1u || a.record_stride == a.record_size) ? 1u : 0u;
+    if (p.packed) {
+        p.pitch = a.record_size;
+        if (b > kMaxPackedRows) b = kMaxPackedRows;
+        if (b > (kStageBytes - 16u) / p.pitch) b = (kStageBytes - 16u) / p.pitch;  // 15 bytes of misalignment + B * R <= 8 192: >= 7 rows, <= 8 loads
+    } else {
+        if (b > (uint32_t)kMaxBatchRows) b = (uint32_t)kMaxBatchRows;
+        if (b > kStageBytes / p.pitch) b = kStageBytes / p.pitch;  // >= 8 (pitch <= 1024)
+    }
     p.batch_rows = b;
-    p.magic = (uint32_t)(0x100000000ull / p.row_bytes) + 1u;    // exact up to one compare for run offsets < 12 * 16 385 < 2^20
+    p.magic = (uint32_t)(0x100000000ull / p.row_bytes) + 1u;    // exact up to one compare for run offsets < 2^20 (<= 12 rows of <= 16 385 bytes, or <= 64 rows within 32 KiB + one row)
     p.n_batches = (uint32_t)(((uint64_t)a.n_variants + b - 1u) / b);
     void (*kern)(EmitArgs, PickParams);
     if (a.kept_idx == nullptr) {
