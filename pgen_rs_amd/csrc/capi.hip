@@ -461,7 +461,13 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             if (ctx->identity) a.kept_idx = nullptr;
             if (a.kept_idx == nullptr) return dispatch_all_samples_lines(ctx, a);
             if (two_pass(ctx, a) && !very_sparse(ctx)) return dispatch_two_pass(ctx, a, sc);
-            if (gt_pick_applicable(a)) {
+            if (gt_lineruns_applicable(a) && a.record_size <= 130u) {
+                // kept subset on SHORT dense records: runs of whole lines through the line-run kernel, picks through its LDS kept table.
+                // Up to N = 520, where a run still holds seven lines or more (its size is set by the record bytes of one wide load):
+                // 0.16 / 0.28-0.34 of roofline at N = 100 / 300 against 0.09 / 0.08-0.24 for the row-by-row pick kernel; from N = 1 000
+                // (four lines per run) the pick kernel is ahead (profiles/r02_kernel_sweeps.md)
+                LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
+            } else if (gt_pick_applicable(a)) {
                 // kept subset on short records: the pick kernel flushes each parked row behind its prefix
                 LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
                 LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
@@ -486,7 +492,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_RUNS:
-            if (!gt_lineruns_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_RUNS (lines) needs all samples kept, dense records, N >= 8 and two lines per item");
+            if (!gt_lineruns_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_RUNS (lines) needs dense records, >= 8 kept samples (of <= 4096 with a keep list) and two lines per item");
             LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_PICK:

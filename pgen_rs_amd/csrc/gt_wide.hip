@@ -716,10 +716,31 @@ __device__ __forceinline__ uint32_t run_text_byte(const uint8_t *slab, uint32_t 
     return gt_text_byte(code, x & 3u);
 }
 
-__device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WideParams &p, const Item &it, const uint8_t *slab, uint8_t *stage,
-                                               uint32_t pdelta, uint32_t lane)
+// kept-subset form (PICK): the 2-bit code of kept rank `rank` of the record at `rec` — `tab` is the block's LDS copy of the ascending
+// kept list as u16 (what filter_metadata src/pfile.rs:319-333 yields), with kTabFront / kTabBack entries of slack around it (ranks
+// -4 .. K + 4 occur next to a line's ends; their bytes are never stored)
+constexpr uint32_t kTabFront = 4, kTabBack = 12, kTabMaxSamples = 4096;
+__device__ __forceinline__ uint32_t tab_code(const uint8_t *rec, const uint16_t *tab, int32_t rank)
 {
-    const int32_t N4 = (int32_t)(4u * a.sample_count);              // GT text bytes of a line, without its '\n'
+    const uint32_t s = (uint32_t)tab[rank];
+    return ((uint32_t)rec[s >> 2] >> ((s & 3u) * 2u)) & 3u;
+}
+
+// 16 text bytes of the line's GT segment from byte x (x >= -15) for a kept list
+__device__ __forceinline__ u32x4 tab_text16(const uint8_t *rec, const uint16_t *tab, int32_t x)
+{
+    const int32_t g = x >> 2;  // floor
+    const uint32_t sh = (uint32_t)x & 3u;
+    const uint32_t t0 = gt_text(tab_code(rec, tab, g)), t1 = gt_text(tab_code(rec, tab, g + 1)), t2 = gt_text(tab_code(rec, tab, g + 2));
+    const uint32_t t3 = gt_text(tab_code(rec, tab, g + 3)), t4 = gt_text(tab_code(rec, tab, g + 4));
+    return u32x4{funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
+}
+
+template <bool PICK>
+__device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WideParams &p, const Item &it, const uint8_t *slab, uint8_t *stage,
+                                               uint32_t pdelta, uint32_t lane, const uint16_t *tab)
+{
+    const int32_t N4 = (int32_t)(4u * a.kept_count);                // GT text bytes of a line, without its '\n'
     const uint32_t R = a.record_size;
     const uint32_t delta = (uint32_t)it.delta;                      // slab offset of the run's first record
     const uint8_t *const pfx = slab + kLrRecBytes + pdelta;         // line r's prefix bytes at pfx + prel[r]
@@ -795,15 +816,20 @@ __device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WidePara
             const int32_t x = o - gt_lo;
             if (x > -16 && x < N4 && rr < nrows) {
                 const uint8_t *const rec = slab + delta + rr * R;
-                uint32_t window;
-                if (x >= 0) {
-                    uint16_t h;
-                    __builtin_memcpy(&h, rec + (x >> 4), 2);
-                    window = h;
+                u32x4 v;
+                if (PICK) {
+                    v = tab_text16(rec, tab, x);
                 } else {
-                    window = (uint32_t)rec[0] << 8;  // record byte -1 (none) and byte 0
+                    uint32_t window;
+                    if (x >= 0) {
+                        uint16_t h;
+                        __builtin_memcpy(&h, rec + (x >> 4), 2);
+                        window = h;
+                    } else {
+                        window = (uint32_t)rec[0] << 8;  // record byte -1 (none) and byte 0
+                    }
+                    v = gt_text16_from_window(window, (int64_t)x);
                 }
-                const u32x4 v = gt_text16_from_window(window, (int64_t)x);
                 st[s4 * 64u + lane] = v4u{v.x, v.y, v.z, v.w};
             }
         }
@@ -826,7 +852,9 @@ __device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WidePara
             }
             if (line_l && adown(gt_lo) < ls && lane >= 48u) {
                 const int32_t ob = gt_lo + (int32_t)(lane - 48u);
-                if (ob < aup(gt_lo) && ob >= glo && ob < lim_hi) stage[ob - gb] = (uint8_t)run_text_byte(slab, delta + l * R, lane - 48u);
+                if (ob < aup(gt_lo) && ob >= glo && ob < lim_hi)
+                    stage[ob - gb] = (uint8_t)(PICK ? gt_text_byte(tab_code(slab + delta + l * R, tab, (int32_t)((lane - 48u) >> 2)), (lane - 48u) & 3u)
+                                                    : run_text_byte(slab, delta + l * R, lane - 48u));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -857,10 +885,15 @@ __device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WidePara
     }
 }
 
-template <int NS>
+template <int NS, bool PICK = false>
 __global__ __launch_bounds__(64 * (NS + 1)) void gt_lineruns_kernel(EmitArgs a, WideParams p)
 {
     constexpr int RS = 2, DS = RS + 1;
+    __shared__ uint16_t s_tab[PICK ? kTabFront + kTabMaxSamples + kTabBack : 1];
+    if (PICK) {
+        for (uint32_t r = threadIdx.x; r < kTabFront + a.kept_count + kTabBack; r += 64u * (NS + 1))
+            s_tab[r] = r >= kTabFront && r < kTabFront + a.kept_count ? (uint16_t)a.kept_idx[r - kTabFront] : (uint16_t)0;
+    }
     __shared__ __attribute__((aligned(16))) uint8_t slabs[NS][RS][kLrSlab];
     __shared__ __attribute__((aligned(16))) uint8_t s_desc[NS][DS][kDescBytes];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[NS][kStageBytes];
@@ -923,7 +956,9 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_lineruns_kernel(EmitArgs a, 
                     po_v[w] = a.prefix_off[jr];
                     const uint32_t nrows = (uint32_t)min((uint64_t)B, (uint64_t)a.n_variants - row0);
                     const uint8_t *const rec = a.records + row0 * (uint64_t)R;
-                    const uint32_t n_bytes = nrows * R + (row0 + nrows < (uint64_t)a.n_variants ? 1u : 0u);
+                    // (+ the first byte of the record behind the run: the first GT bytes of that line may share the run's last chunk; with a
+                    // kept list its first kept samples can sit anywhere in the record, so the whole record comes along)
+                    const uint32_t n_bytes = nrows * R + (row0 + nrows < (uint64_t)a.n_variants ? (PICK ? R : 1u) : 0u);
                     const uint32_t mis = (uint32_t)((uint64_t)(uintptr_t)rec & 15ull);
                     const uint32_t n_load = (mis + n_bytes + 15u) / 16u;   // <= 66
                     if (lane < n_load) in0[w] = *reinterpret_cast<const v4u *>(rec - mis + lane * 16u);
@@ -1023,7 +1058,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_lineruns_kernel(EmitArgs a, 
             if (t != kNoItem) {
                 const Item it = desc_get_item(desc);
                 const uint32_t pdelta = sgpr32(*reinterpret_cast<const uint32_t *>(desc + 52));
-                emit_lines_run(a, p, it, slab, s_stage[w], pdelta, lane);
+                emit_lines_run<PICK>(a, p, it, slab, s_stage[w], pdelta, lane, s_tab + (PICK ? kTabFront : 0u));
             }
             if (lane == 0u) lds_flag_write(lds_offset(&s_done[w][slot]), step + 1u);
         }
@@ -1170,6 +1205,7 @@ static uint32_t lineruns_rows_for(const EmitArgs &a)
     const uint32_t row_text = 4u * a.kept_count + 1u;
     const uint32_t max_prefix = (uint32_t)a.max_line_bytes - row_text;
     uint32_t b = 1040u / a.record_size;                                        // one wide load of the run's records (+ 1 byte)
+    if (a.kept_idx && b) b--;                                                   // kept list: + the whole record behind the run
     b = std::min<uint32_t>(b, 15328u / (uint32_t)a.max_line_bytes);            // the run's chunks (+ lead) fit one span
     b = std::min<uint32_t>(b, kLrMaxRows);
     if (max_prefix) b = std::min<uint32_t>(b, (kLrPfxBytes - 16u) / max_prefix - (((kLrPfxBytes - 16u) / max_prefix) ? 1u : 0u));  // prefixes of B + 1 lines
@@ -1178,7 +1214,10 @@ static uint32_t lineruns_rows_for(const EmitArgs &a)
 
 bool gt_lineruns_applicable(const EmitArgs &a)
 {
-    return a.kept_idx == nullptr && a.line_off != nullptr && a.prefix_off != nullptr && !gathered(a) && a.sample_count >= 8u &&
+    // all samples, or a kept list of >= 8 samples out of <= 4 096 (its u16 copy lives in LDS); lines of >= 33 bytes of GT text (a
+    // 16-byte chunk meets at most one '\n'); dense records; at least two lines per item
+    const bool samples_ok = a.kept_idx == nullptr ? a.sample_count >= 8u : (a.sample_count <= kTabMaxSamples && a.kept_count >= 8u);
+    return samples_ok && a.line_off != nullptr && a.prefix_off != nullptr && !gathered(a) &&
            (a.n_variants <= 1 || a.record_stride == a.record_size) && a.work_counters != nullptr && lineruns_rows_for(a) >= 2u;
 }
 
@@ -1205,7 +1244,7 @@ hipError_t launch_gt_lineruns(const EmitArgs &a, const Tuning &t, int num_cus, h
     // (profiles/r02_kernel_sweeps.md; the GT-only RUNS mode, one round trip and a lighter loader, stays best with seven)
     constexpr int kStorers = 3;
     const uint64_t need = (p.n_items + (uint64_t)kStorers - 1ull) / (uint64_t)kStorers;
-    void (*dk)(EmitArgs, WideParams) = gt_lineruns_kernel<kStorers>;
+    void (*dk)(EmitArgs, WideParams) = a.kept_idx ? gt_lineruns_kernel<kStorers, true> : gt_lineruns_kernel<kStorers, false>;
     constexpr int threads = 64 * (kStorers + 1);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;

@@ -564,23 +564,31 @@ def test_emit_lines_long_rows_long_prefixes(n):
         assert (got[: out_off + lead_gap] == SENTINEL).all() and (got[out_off + lead_gap + want.size :] == SENTINEL).all(), f"n={n} v={v} wrote outside"
 
 
+@pytest.mark.parametrize("keep", [None, 0.5, 0.1])
 @pytest.mark.parametrize("n", [8, 9, 33, 61, 100, 300, 301, 302, 303, 500, 1000, 1023, 1500, 1900])
-def test_emit_lines_runs_of_lines(n):
+def test_emit_lines_runs_of_lines(n, keep):
     """Full lines on SHORT rows through the line-run kernel (a run of lines per work item, prefixes + GT text + '\n' assembled
     in LDS, whole-line stores): prefixes of 0..40 bytes (empty ones too, so GT segments start at every byte phase and seams fall
     everywhere in a chunk), V = 1, V smaller than a run, many runs per block, forced 2- and 3-line runs, unaligned output and
     record pointers, a first line that does not start at output byte 0; sentinel bytes around the output."""
     rng = np.random.default_rng(9100 + n)
     r = oracle.variant_record_size(n)
+    kept = None
+    if keep is not None:
+        # kept-subset form: the picks go through the block's LDS copy of the kept list (>= 8 kept samples)
+        if int(n * keep) < 8:
+            pytest.skip("fewer than 8 kept samples")
+        kept = np.sort(rng.choice(n, size=int(n * keep), replace=False)).astype(np.uint32)
+    k = n if kept is None else int(kept.size)
     for v, out_off, rec_off, rows_knob, lead_gap, pmax in ((1, 0, 0, 0, 0, 40), (2, 5, 3, 0, 0, 40), (9, 15, 1, 2, 7, 25), (257, 16, 15, 3, 0, 40),
                                                              (3001, 127, 7, 0, 0, 12), (7001, 1, 0, 0, 3, 40)):
         recs = rng.integers(0, 256, size=rec_off + v * r, dtype=np.uint8)
         prefixes = [bytes(rng.integers(33, 127, size=int(rng.integers(0, pmax + 1)) if i % 5 else 0, dtype=np.uint8)) for i in range(v)]
         blob = np.frombuffer(b"?" * 3 + b"".join(prefixes) + b"!", dtype=np.uint8)      # the blob does not start at a prefix either
         poff = (3 + np.cumsum([0] + [len(q) for q in prefixes])).astype(np.int64)
-        loff = (lead_gap + np.cumsum([0] + [len(q) + 4 * n + 1 for q in prefixes])).astype(np.int64)
-        want = oracle.emit_lines(recs[rec_off:], v, n, blob, poff.astype(np.uint64), (loff - lead_gap).astype(np.uint64))
-        with pgen_rs_amd.GtEngine(n, device=0) as eng:
+        loff = (lead_gap + np.cumsum([0] + [len(q) + 4 * k + 1 for q in prefixes])).astype(np.int64)
+        want = oracle.emit_lines(recs[rec_off:], v, n, blob, poff.astype(np.uint64), (loff - lead_gap).astype(np.uint64), kept_idx=kept)
+        with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
             eng.tune(_capi.KNOB_RUNS_ROWS, rows_knob)
             if v > 5000:
                 eng.tune(_capi.KNOB_WIDE_BLOCKS_PER_CU, 1)
@@ -589,14 +597,16 @@ def test_emit_lines_runs_of_lines(n):
                 eng.emit_lines(torch.from_numpy(recs).to(DEV), v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV),
                                torch.from_numpy(loff).to(DEV), pmax, out[out_off:], kernel=_capi.KERNEL_RUNS, records_offset=rec_off)
             except pgen_rs_amd.PgenHipError:
-                assert n > 1900 or 4 * n + 1 + pmax > 7664, "line-run kernel refused a shape it should take"
+                # refusals that are in order: fewer than two lines per item (one wide load holds the run's records — and, with a kept
+                # list, the whole record behind the run), or a line too long for half a span
+                assert 1040 // r - (0 if kept is None else 1) < 2 or 4 * k + 1 + pmax > 7664, "line-run kernel refused a shape it should take"
                 continue
             eng.wait()
             got = out.cpu().numpy()
         body = got[out_off + lead_gap : out_off + lead_gap + want.size]
         if bytes(body) != want.tobytes():
             bad = np.flatnonzero(body != want)
-            raise AssertionError(f"n={n} v={v} out_off={out_off} rec_off={rec_off} rows={rows_knob} gap={lead_gap}: {bad.size} bytes differ, first at {bad[:8]}")
+            raise AssertionError(f"n={n} k={k} v={v} out_off={out_off} rec_off={rec_off} rows={rows_knob} gap={lead_gap}: {bad.size} bytes differ, first at {bad[:8]}")
         assert (got[: out_off + lead_gap] == SENTINEL).all() and (got[out_off + lead_gap + want.size :] == SENTINEL).all()
 
 
