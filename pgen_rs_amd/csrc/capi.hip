@@ -461,11 +461,11 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             if (ctx->identity) a.kept_idx = nullptr;
             if (a.kept_idx == nullptr) return dispatch_all_samples_lines(ctx, a);
             if (two_pass(ctx, a) && !very_sparse(ctx)) return dispatch_two_pass(ctx, a, sc);
-            if (gt_lineruns_applicable(a) && a.record_size <= 130u) {
+            if (gt_lineruns_applicable(a) && gt_lineruns_rows(a) >= 7u) {
                 // kept subset on SHORT dense records: runs of whole lines through the line-run kernel, picks through its LDS kept table.
-                // Up to N = 520, where a run still holds seven lines or more (its size is set by the record bytes of one wide load):
-                // 0.16 / 0.28-0.34 of roofline at N = 100 / 300 against 0.09 / 0.08-0.24 for the row-by-row pick kernel; from N = 1 000
-                // (four lines per run) the pick kernel is ahead (profiles/r02_kernel_sweeps.md)
+                // While a run holds seven lines or more (records of one wide load: N <= 520; prefixes of the slab's prefix area: up to
+                // ~90 bytes): 0.16-0.24 / 0.28-0.34 of roofline at N = 100 / 300 against 0.09-0.14 / 0.08-0.24 for the row-by-row pick
+                // kernel; with shorter runs the pick kernel is ahead (profiles/r02_kernel_sweeps.md)
                 LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
             } else if (gt_pick_applicable(a)) {
                 // kept subset on short records: the pick kernel flushes each parked row behind its prefix

@@ -1212,6 +1212,8 @@ static uint32_t lineruns_rows_for(const EmitArgs &a)
     return b;
 }
 
+uint32_t gt_lineruns_rows(const EmitArgs &a) { return lineruns_rows_for(a); }
+
 bool gt_lineruns_applicable(const EmitArgs &a)
 {
     // all samples, or a kept list of >= 8 samples out of <= 4 096 (its u16 copy lives in LDS); lines of >= 33 bytes of GT text (a

@@ -67,6 +67,7 @@ hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
 // Runs of FULL LINES (line_off / prefix_off set) on short rows, all samples kept, dense records: prefixes, GT text and '\n' of a
 // run of lines assembled in the storers' LDS stages and stored as whole 128-B lines (gt_wide.hip, gt_lineruns_kernel).
 bool gt_lineruns_applicable(const EmitArgs &a);
+uint32_t gt_lineruns_rows(const EmitArgs &a);  // lines per work item for this shape (records of one wide load, prefix bytes of the slab, one span of text)
 hipError_t launch_gt_lineruns(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream);
 
 // Kept-subset segment kernels: number of kept samples before each segment of kScanSegmentSamples samples.
