@@ -137,8 +137,15 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
 
     v4u buf[kMaxBatchRows];
     const bool packed = p.packed != 0u;
+    // full-line mode: where row (batch row0 + lane)'s GT segment starts in the output (line_off + prefix length), fetched with the
+    // batch's records — one coalesced load per batch instead of three dependent scalar loads in front of every row's flush
+    uint64_t text_off = 0ull;
     auto load_batch = [&](uint32_t b) {
         const uint64_t row0 = (uint64_t)b * B;
+        if (LINES) {
+            const uint64_t jr = min(row0 + (uint64_t)lane, (uint64_t)a.n_variants - 1ull);
+            text_off = a.line_off[jr] + (a.prefix_off[jr + 1ull] - a.prefix_off[jr]);
+        }
         if (packed) {
             // the batch's records as one byte run, from the 16-B boundary below its first byte
             const uint8_t *__restrict__ run0 = a.records + row0 * (uint64_t)R;
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
                 *reinterpret_cast<v4u *>(stage + (uint32_t)i * p.pitch + lane * 16u) = x;
             }
         }
+        const uint64_t text_off_cur = text_off;   // (this batch's; load_batch below overwrites it with the next batch's)
         const uint32_t bi_next = bi + batch_step;
         const bool more = bi_next < p.n_batches;
         if (more) load_batch(bi_next);
@@ -204,7 +212,9 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
             for (uint32_t i = 0; i < rows_here; i++) {
                 const uint8_t *row = rows0 + i * p.pitch;
                 const uint16_t *idx = s_idx;
-                flush_codes([row, idx, K](uint32_t r) { return pick_code<IDENT>(row, idx, (int32_t)r, K); }, 0u, row_text(a, row0 + i), 0ull,
+                const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(text_off_cur >> 32), (int)i) << 32) |
+                                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)text_off_cur, (int)i);
+                flush_codes([row, idx, K](uint32_t r) { return pick_code<IDENT>(row, idx, (int32_t)r, K); }, 0u, a.out + off, 0ull,
                             (uint64_t)S, 0u, K, lane);
             }
             if (!more) break;
