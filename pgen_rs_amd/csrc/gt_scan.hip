@@ -125,8 +125,12 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     const uint32_t tail_b = tail_t * 1024u + lane * 16u;
     const uint32_t tail_off = min(tail_b, R - 16u);
     const uint32_t tail_shift = tail_b + 16u <= R ? 0u : min(tail_b - (R - 16u), 16u);
-    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg], uint32_t &fbyte) {
+    // (full lines: where the row's GT segment starts — line_off + prefix length — travels with the row's loads, a row ahead,
+    // instead of three dependent loads in front of every flush)
+    const bool lines = !COMPACT && a.line_off != nullptr;
+    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg], uint32_t &fbyte, uint64_t &toff) {
         const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
+        if (lines) toff = a.line_off[row] + (a.prefix_off[row + 1ull] - a.prefix_off[row]);
         const uint8_t *__restrict__ rec = HAS_VIDX ? gathered_record(a, row) : a.records + row * a.record_stride;
         const uint8_t *__restrict__ sub = rec + (uint64_t)tile0 * 1024u;
 #pragma unroll
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
         }
         if (COMPACT && lane < n_foreign) fbyte = rec[f_smp >> 2];  // the record byte of a rank behind the slice (a later segment's sample)
     };
-    auto emit_row = [&](uint64_t n, const v4u(&w)[kTilesPerSeg], uint32_t fbyte) {
+    auto emit_row = [&](uint64_t n, const v4u(&w)[kTilesPerSeg], uint32_t fbyte, uint64_t toff) {
         // park the row's segment bytes (segment byte b at stage[b])
 #pragma unroll
         for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
             __builtin_amdgcn_wave_barrier();
             return;
         }
-        uint8_t *const row_out = row_text(a, j0 + n * row_step);
+        uint8_t *const row_out = lines ? a.out + toff : a.out + (j0 + n * row_step) * a.out_stride;
         const uint64_t lo_emit = 4ull * seg_k0;
         const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
         const uint16_t *idx = s_idx;
@@ -197,15 +201,16 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     // (three buffers, re-loaded three rows ahead, measured no better: 3.20-3.35 vs 3.03-3.20 ms on the config-5 geometry)
     v4u b0[kTilesPerSeg], b1[kTilesPerSeg];
     uint32_t f0 = 0u, f1 = 0u;
-    load_row(0ull, b0, f0);
+    uint64_t t0 = 0ull, t1 = 0ull;
+    load_row(0ull, b0, f0, t0);
     for (uint64_t n = 0;;) {
         landed(b0);
-        load_row(n + 1ull, b1, f1);
-        emit_row(n, b0, f0);
+        load_row(n + 1ull, b1, f1, t1);
+        emit_row(n, b0, f0, t0);
         if (++n == rows) break;
         landed(b1);
-        load_row(n + 1ull, b0, f0);
-        emit_row(n, b1, f1);
+        load_row(n + 1ull, b0, f0, t0);
+        emit_row(n, b1, f1, t1);
         if (++n == rows) break;
     }
 }
