@@ -293,9 +293,11 @@ static int dispatch_all_samples_lines(pgenhip_ctx *ctx, const EmitArgs &a)
     if (gt_wide_lines_applicable(a)) {
         // rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place behind their prefixes (+ a small prefix copy)
         LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
-    } else if (gt_lineruns_applicable(a)) {
-        // short rows, dense records: runs of whole lines (prefix + GT + '\n') assembled in LDS and stored as whole 128-B lines:
-        // 0.30 / 0.44 / 0.49 of roofline at N = 100 / 300 / 1 000 against 0.13 / 0.25 / 0.45 for the row-by-row pick kernel below
+    } else if (gt_lineruns_applicable(a) && (gt_lineruns_rows(a) >= 7u || a.sample_count >= 500u)) {
+        // short rows, dense records: runs of whole lines (prefix + GT + '\n') assembled in LDS and stored as whole 128-B lines.
+        // Ahead of the row-by-row pick kernel below while a run holds seven lines or more (prefixes up to ~90 bytes): 0.30 / 0.43 of
+        // roofline at N = 100 / 300 with 30-byte prefixes against 0.24 / 0.38; with 166-byte prefixes a run is three lines and the
+        // pick kernel (packed batches, text offsets fetched per batch) is ahead below N = 500: 0.23 / 0.33 against 0.14 / 0.29
         // (profiles/r02_kernel_sweeps.md)
         LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
     } else if (gt_pick_applicable(a)) {
