@@ -199,7 +199,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
  * value 0 restores the built-in default of a knob unless noted. */
 typedef enum pgenhip_knob {
     PGENHIP_KNOB_WIDE_BLOCKS_PER_CU = 1, /* stream kernel: resident blocks per CU (default: occupancy API) */
-    PGENHIP_KNOB_WIDE_RANGES = 2,        /* stream kernel: work-queue ranges 1, 2 (default), 4, 8 */
+    PGENHIP_KNOB_WIDE_RANGES = 2,        /* stream kernel: work-queue ranges (write fronts of a launch), a power of two up to 64; default 0 = by shape (8 for rows of more than 16 KiB of text, else 2) */
     PGENHIP_KNOB_FLAT_BLOCKS_PER_CU = 3, /* flat kernel: grid cap per CU (default 64) */
     PGENHIP_KNOB_SCAN_BLOCKS_PER_CU = 4, /* segment kernel: resident blocks per CU (default: 2 from ~0.6 % kept, else the occupancy API's 3) */
     /* 5 was the band override of round 1's three-segment gather kernel (removed) */

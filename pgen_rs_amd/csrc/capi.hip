@@ -76,7 +76,7 @@ bool two_pass_shape(uint32_t sample_count, uint32_t kept_count)
            (uint64_t)kept_count * 22ull <= (uint64_t)sample_count;
 }
 
-constexpr size_t kWorkBlockBytes = 9u * 128u;  // 8 heads 128 B apart + the exit counter
+constexpr size_t kWorkBlockBytes = (kMaxQueueRanges + 1u) * 128u;  // the heads 128 B apart + the exit counter
 constexpr size_t kWorkBlockWords = kWorkBlockBytes / sizeof(uint64_t);
 
 }  // namespace
@@ -515,7 +515,7 @@ int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value)
     switch (knob) {
         case PGENHIP_KNOB_WIDE_BLOCKS_PER_CU: t.wide_blocks_per_cu = value > 0 ? value : d.wide_blocks_per_cu; break;
         case PGENHIP_KNOB_WIDE_RANGES:
-            if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(PGENHIP_ERR_BAD_ARG, "ranges must be 1, 2, 4 or 8");
+            if (value < 0 || value > (int32_t)kMaxQueueRanges || (value & (value - 1)) != 0) return fail(PGENHIP_ERR_BAD_ARG, "ranges must be a power of two up to 64");
             t.wide_ranges = value ? value : d.wide_ranges;
             break;
         case PGENHIP_KNOB_FLAT_BLOCKS_PER_CU: t.flat_blocks_per_cu = value > 0 ? value : d.flat_blocks_per_cu; break;

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
 
     if (wave == 0u) {
         // ------------------------------ loader wave ------------------------------
-        const uint32_t nr = p.n_ranges;  // power of two <= 8
+        const uint32_t nr = p.n_ranges;  // power of two <= kMaxQueueRanges
         const uint64_t per_range = (p.n_items + (uint64_t)nr - 1ull) / (uint64_t)nr;
         uint32_t range = blockIdx.x & (nr - 1u);
         uint32_t drained = 0u;  // consecutive ranges found empty
@@ -658,12 +658,13 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
         }
         // ---- self-cleaning queue: the last loader wave to leave re-zeroes the heads for the next launch (every block's
         // claims precede its exit count; no memset node in front of the kernel, and a captured graph can be replayed)
-        if (lane == 0u) {
-            unsigned long long *const exits = reinterpret_cast<unsigned long long *>(a.work_counters + 8u * 16u);
-            if (atomicAdd(exits, 1ull) == (unsigned long long)gridDim.x - 1ull) {
-#pragma unroll
-                for (uint32_t h = 0; h < 8u; h++) atomicExch(reinterpret_cast<unsigned long long *>(a.work_counters + h * 16u), 0ull);
-                atomicExch(exits, 0ull);
+        {
+            unsigned long long *const exits = reinterpret_cast<unsigned long long *>(a.work_counters + kMaxQueueRanges * 16u);
+            uint32_t last = 0u;
+            if (lane == 0u) last = atomicAdd(exits, 1ull) == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;
+            if (__builtin_amdgcn_readfirstlane(last)) {
+                if (lane < kMaxQueueRanges) atomicExch(reinterpret_cast<unsigned long long *>(a.work_counters + lane * 16u), 0ull);   // lane h: head h
+                if (lane == 0u) atomicExch(exits, 0ull);
             }
         }
     } else {
@@ -1036,12 +1037,13 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_lineruns_kernel(EmitArgs a, 
             }
             if (t0 == kNoItem) break;
         }
-        if (lane == 0u) {
-            unsigned long long *const exits = reinterpret_cast<unsigned long long *>(a.work_counters + 8u * 16u);
-            if (atomicAdd(exits, 1ull) == (unsigned long long)gridDim.x - 1ull) {
-#pragma unroll
-                for (uint32_t h = 0; h < 8u; h++) atomicExch(reinterpret_cast<unsigned long long *>(a.work_counters + h * 16u), 0ull);
-                atomicExch(exits, 0ull);
+        {
+            unsigned long long *const exits = reinterpret_cast<unsigned long long *>(a.work_counters + kMaxQueueRanges * 16u);
+            uint32_t last = 0u;
+            if (lane == 0u) last = atomicAdd(exits, 1ull) == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;
+            if (__builtin_amdgcn_readfirstlane(last)) {
+                if (lane < kMaxQueueRanges) atomicExch(reinterpret_cast<unsigned long long *>(a.work_counters + lane * 16u), 0ull);   // lane h: head h
+                if (lane == 0u) atomicExch(exits, 0ull);
             }
         }
     } else {
@@ -1118,7 +1120,6 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     p.total_bytes = (uint64_t)a.n_variants * p.row_bytes;
     p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 127ull);
     // interleaved in one process (profiles/r01_kernel_sweeps.md, chr22 block): 8 ranges 2.058 ms, 4: 2.045, 2: 2.038, 1: 2.039
-    p.n_ranges = t.wide_ranges == 1 || t.wide_ranges == 4 || t.wide_ranges == 8 ? (uint32_t)t.wide_ranges : 2u;
     p.run_rows = 0u;
     p.run_rec = 0u;
     p.magic = 0u;
@@ -1127,6 +1128,11 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     const uint64_t max_row_chunks = (p.row_bytes + 15ull) / 16ull + 1ull + 63ull;
     p.spans_per_row = (uint32_t)((max_row_chunks + kSpanChunks - 1ull) / kSpanChunks);
     p.n_items = (uint64_t)a.n_variants * p.spans_per_row;
+    // Write fronts of the launch (set below, once the grid is known).  Rows of several spans on a launch of >= 64 steps per block: 8 ranges — on the 212-GB launch of BASELINE configs[2] two fronts ran at 0.73
+    // or 0.78 of roofline depending on where the driver had put the buffer (stable per allocation, 5-7 % apart), eight at 0.784 on
+    // every box; 0.765 -> 0.784 on the 266-GB shard of configs[3]; +0.4-2.4 % on 12-GB launches of N = 5 000 .. 100 000.  Rows of one
+    // span (the chr22 shape): 2 — four or eight were level on one box and 1.6-2.4 % behind on another; short launches (the 0.8-GB second
+    // pass of the two-pass path: 15 steps per block): 2 — eight cost 9 % there (profiles/r02_kernel_sweeps.md).
 
     // 1 loader + 7 storer waves, nontemporal stores, plain store steps in bursts of 2 (text of both first, then both
     // stores): the measured best of the round-1 A/Bs (3 storers, plain stores, bursts of 1/4/8: profiles/r01_kernel_sweeps.md)
@@ -1144,6 +1150,7 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     if (t.wide_blocks_per_cu > 0) per_cu = t.wide_blocks_per_cu;
     const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
     const uint32_t g = (uint32_t)(need < cap ? need : cap);
+    p.n_ranges = t.wide_ranges > 0 ? (uint32_t)t.wide_ranges : (p.spans_per_row > 1u && need >= 64ull * g ? 8u : 2u);
     hipLaunchKernelGGL(dk, dim3(g), dim3(512), 0, stream, a, p);
     if (a.line_off) return launch_copy_prefixes(a, num_cus, stream);  // the prefixes: disjoint bytes, same stream, any order
     return hipGetLastError();
@@ -1182,7 +1189,7 @@ hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     p.row_bytes = 4ull * a.kept_count + 1ull;
     p.total_bytes = (uint64_t)a.n_variants * p.row_bytes;
     p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 127ull);
-    p.n_ranges = t.wide_ranges == 1 || t.wide_ranges == 4 || t.wide_ranges == 8 ? (uint32_t)t.wide_ranges : 2u;
+    p.n_ranges = t.wide_ranges > 0 ? (uint32_t)t.wide_ranges : 2u;   // (1 .. 64 measured level in this mode)
     p.spans_per_row = 1u;
     p.run_rows = t.runs_rows > 0 && (uint32_t)t.runs_rows < run_rows_for(a) ? (uint32_t)t.runs_rows : run_rows_for(a);
     p.run_rec = a.record_size;
@@ -1231,7 +1238,7 @@ hipError_t launch_gt_lineruns(const EmitArgs &a, const Tuning &t, int num_cus, h
     p.row_bytes = 4ull * a.kept_count + 1ull;
     p.total_bytes = 0ull;
     p.head = (uint32_t)(((uint64_t)(uintptr_t)a.out) & 127ull);
-    p.n_ranges = t.wide_ranges == 1 || t.wide_ranges == 4 || t.wide_ranges == 8 ? (uint32_t)t.wide_ranges : 2u;
+    p.n_ranges = t.wide_ranges > 0 ? (uint32_t)t.wide_ranges : 2u;   // (1 .. 64 measured level in this mode)
     p.spans_per_row = 1u;
     const uint32_t b_max = lineruns_rows_for(a);
     p.run_rows = t.runs_rows > 0 && (uint32_t)t.runs_rows < b_max ? (uint32_t)t.runs_rows : b_max;

@@ -27,12 +27,16 @@ struct EmitArgs {
     uint64_t *work_counters;      // device scratch owned by the ctx, one block per launch in flight: 8 x 128-B-spaced work-queue heads + a block-exit counter at +1024 B; zero between launches (the last block out re-zeroes them)
 };
 
+// Work-queue kernels: up to kMaxQueueRanges contiguous item ranges per launch, one 128-B-spaced head word each, and the block-exit
+// counter behind them (a launch's counter block: (kMaxQueueRanges + 1) * 128 bytes; capi.hip keeps a ring of them)
+constexpr uint32_t kMaxQueueRanges = 64;
+
 // Launch-shape knobs, resolved ONCE per context: pgenhip_create sets the measured defaults below and
 // pgenhip_tune overrides one (tests force small grids to exercise ring reuse; A/B probes).  Nothing on the
 // launch path reads the process environment.
 struct Tuning {
     int wide_blocks_per_cu = 0;    // stream kernel: 0 = what the occupancy API says is resident
-    int wide_ranges = 2;           // stream kernel: work-queue ranges (1, 2, 4 or 8)
+    int wide_ranges = 0;           // stream kernel: work-queue ranges = write fronts of a launch (power of two <= 64); 0 = by shape (8 for rows of several spans, else 2)
     int flat_blocks_per_cu = 64;   // flat kernel: grid cap
     int scan_blocks_per_cu = 0;    // segment kernel: 0 = the measured rule (2 from ~0.6 % kept, else what the occupancy API says)
     int pick_batch_bytes = 32768;  // short-record pick kernel: text per batch (one store drain per batch)

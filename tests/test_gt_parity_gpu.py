@@ -438,7 +438,7 @@ def test_hip_graph_capture_and_replay(n, kept_frac):
 
 def test_tune_rejects_unknown_knobs_and_values():
     with pgen_rs_amd.GtEngine(2504, device=0) as eng:
-        for knob, value in ((99, 1), (_capi.KNOB_WIDE_RANGES, 3), (0, 0)):
+        for knob, value in ((99, 1), (_capi.KNOB_WIDE_RANGES, 3), (_capi.KNOB_WIDE_RANGES, 128), (_capi.KNOB_WIDE_RANGES, -2), (0, 0)):
             with pytest.raises(pgen_rs_amd.PgenHipError) as ei:
                 eng.tune(knob, value)
             assert ei.value.status == _capi.ERR_BAD_ARG
@@ -739,7 +739,7 @@ def test_large_shape_properties_config3_rows():
     assert rows.tobytes() == oracle.decode_emit(host, v, n).tobytes()
 
 
-@pytest.mark.parametrize("ranges,per_cu", [(1, 2), (2, 2), (4, 1), (8, 3), (2, 0)])
+@pytest.mark.parametrize("ranges,per_cu", [(1, 2), (2, 2), (4, 1), (8, 3), (2, 0), (0, 0), (16, 1), (64, 2)])
 def test_wide_kernel_variants(ranges, per_cu):
     """The work-queue stream kernel (1 loader + 7 storer waves) against the oracle with every number of queue
     ranges and several grid sizes, on shapes with 1 and several spans per row."""
@@ -870,7 +870,7 @@ def test_config5_geometry_500k_samples_keep_1pct(path, v):
 _CONFIG5_DIGEST = {}
 
 
-@pytest.mark.parametrize("ranges", [1, 2, 8])
+@pytest.mark.parametrize("ranges", [1, 2, 8, 32])
 def test_wide_kernel_many_steps_ring_reuse(ranges):
     """Enough items per block that the loader/storer LDS ring is reused many times and the work queue
     is drained and stolen from (one block per CU, 20 000 rows), whole output compared with the oracle."""
