@@ -71,7 +71,7 @@ constexpr uint32_t kPickMaxSegCodes = kSegSamples;             // up to a fully 
 // rank slice [k0, k1) and fetches the up to three ranks behind k1 that share its last byte straight from the record (their
 // samples live in later segments) — no byte is written twice, nothing needs zeroing.
 template <bool HAS_VIDX, bool COMPACT = false>
-__global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups, uint32_t xcd_groups)
+__global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups, uint32_t xcd_groups, uint32_t bands)
 {
     __shared__ uint16_t s_idx[kPickMaxSegCodes + 8];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
@@ -93,9 +93,15 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     const uint32_t seg_cnt = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg + 1u]) - seg_k0;
     const bool last_seg = seg + 1u == n_seg;
     const uint32_t R = a.record_size;
-    const uint64_t row_step = (uint64_t)row_groups * kWaves;
-    const uint64_t j0 = (uint64_t)row_group * kWaves + wave;
-    const uint64_t rows = j0 < a.n_variants ? (a.n_variants - j0 + row_step - 1ull) / row_step : 0ull;
+    // BANDS: the launch's rows are cut into `bands` contiguous bands and row group g works in band g % bands (with the XCD map: one
+    // band per XCD), so the launch reads (and writes) at `bands` distant fronts instead of one window of row_groups * 4 rows that
+    // all blocks share — where the driver put the buffers then matters less (see the write fronts of the stream kernel, gt_wide.hip)
+    const uint32_t band = row_group % bands, group_in_band = row_group / bands;
+    const uint64_t band_rows = ((uint64_t)a.n_variants + bands - 1u) / bands;
+    const uint64_t band_lo = (uint64_t)band * band_rows, band_hi = min((uint64_t)a.n_variants, band_lo + band_rows);
+    const uint64_t row_step = (uint64_t)(row_groups / bands) * kWaves;
+    const uint64_t j0 = band_lo + (uint64_t)group_in_band * kWaves + wave;
+    const uint64_t rows = j0 < band_hi ? (band_hi - j0 + row_step - 1ull) / row_step : 0ull;
 
     if (seg_cnt == 0u) {
         // nothing of this segment is kept; the last segment still owes every row its '\n' (:190)
@@ -240,7 +246,7 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
     // two blocks per CU the pick kernel is ahead there too: 1.5 % kept 1.85 vs 1.99 ms, profiles/r02_kernel_sweeps.md).
     // Blocks per CU: the occupancy API says 3 (32 KiB table + 16 KiB of stages); from ~0.6 % kept upwards 2 measure the same or
     // better (+5-9 % at 1-3 % kept, level from 30 %), below that 3 do (the kernel is then a pure record reader).
-    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t);
+    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t, uint32_t);
     if (compact)  // first pass of the two-pass path: a.out / a.out_stride address the compact records (ceil(K / 4) bytes per row)
         kern = gathered(a) ? gt_scan_pick_kernel<true, true> : gt_scan_pick_kernel<false, true>;
     else
@@ -251,7 +257,12 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
     if (groups > groups_needed) groups = groups_needed;
     const uint32_t xcd_groups = t.scan_xcd_map != 0 ? (uint32_t)(groups & ~7ull) : 0u;
     const uint32_t grid = (uint32_t)(groups * n_seg_eff);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, sc, n_seg_eff, (uint32_t)groups, xcd_groups);
+    // Eight bands where the text dominates the traffic (>= 10 % kept: N = 500 000, 10 % kept 0.599 -> 0.626 of roofline, 50 % 0.589 ->
+    // 0.593); one front where the launch is mostly a record reader (1 % kept, compact pass: 0.634 vs 0.614 banded; 0.3 % single pass:
+    // 0.741 vs 0.693) — reads like the one narrow window, writes like several fronts (profiles/r02_kernel_sweeps.md)
+    const bool banded = !compact && (uint64_t)a.kept_count * 10ull >= (uint64_t)a.sample_count && groups % 8ull == 0ull && groups_needed >= 64ull * groups;
+    const uint32_t bands = banded ? 8u : 1u;   // (every band holds the same number of row groups)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, sc, n_seg_eff, (uint32_t)groups, xcd_groups, bands);
     return hipGetLastError();
 }
 
