@@ -1069,20 +1069,43 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_lineruns_kernel(EmitArgs a, 
 
 // ---------------------------------------------------------------------------------------------
 // copy_prefixes_kernel — LINES mode: line j's prefix bytes (pvar fields + "GT", src/pfile.rs:157-161)
-// from the blob to out + line_off[j].  1-2 % of the output bytes; a quarter wave per line so four
-// lines are in flight per wave, byte granular because the neighbouring GT bytes belong to the stream
-// kernel's waves.
-__global__ __launch_bounds__(256) void copy_prefixes_kernel(EmitArgs a)
+// from the blob to out + line_off[j].  1-2 % of the output bytes with plink2-made .pvar files, 1.6 % + with 1000 Genomes INFO
+// columns (130-250 bytes per line), byte granular at both ends because the neighbouring GT bytes belong to other waves.
+// A wave takes 64 consecutive lines per round: their offsets with ONE coalesced load each (no dependent load chain per line),
+// then eight or four lines per pass (8 / 16 lanes each, by the longest prefix): whole destination-aligned dwords (the four source bytes gathered), the up to three
+// bytes before and behind them as bytes.  (The first version — a quarter wave per line, three dependent offset loads and a byte
+// loop — took 0.20 ms beside the stream kernel's 1.89 ms on 1 M lines of 2 504 samples with 166-byte prefixes.)
+// `shift`: log2 of the lanes per line (3: eight lanes for prefixes up to 48 bytes, else 4: sixteen)
+__global__ __launch_bounds__(256) void copy_prefixes_kernel(EmitArgs a, uint32_t shift)
 {
-    const uint32_t sub = threadIdx.x & 15u;
-    const uint64_t quarter = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const uint64_t n_quarters = ((uint64_t)gridDim.x * blockDim.x) >> 4;
-    for (uint64_t j = quarter; j < a.n_variants; j += n_quarters) {
-        const uint64_t p0 = a.prefix_off[j];
-        const uint64_t len = a.prefix_off[j + 1ull] - p0;
-        const uint8_t *__restrict__ src = a.prefix_blob + p0;
-        uint8_t *__restrict__ dst = a.out + a.line_off[j];
-        for (uint64_t b = sub; b < len; b += 16ull) dst[b] = src[b];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t group = lane >> shift, sub = lane & ((1u << shift) - 1u), per_pass = 64u >> shift, lanes = 1u << shift;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t V = a.n_variants;
+    for (uint64_t base = wave * 64ull; base < V; base += n_waves * 64ull) {
+        const uint64_t j = min(base + (uint64_t)lane, V - 1ull);
+        const uint64_t p0_l = a.prefix_off[j];
+        const uint32_t len_l = (uint32_t)(a.prefix_off[j + 1ull] - p0_l);
+        const uint64_t lo_l = a.line_off[j];
+        const uint32_t count = (uint32_t)min(64ull, V - base);
+        for (uint32_t i = 0; i < count; i += per_pass) {
+            const uint32_t li = min(i + group, count - 1u);      // (a short last pass: the spare groups repeat the last line, same bytes)
+            const uint64_t p0 = (uint64_t)__shfl((unsigned long long)p0_l, (int)li, 64);
+            const uint32_t len = (uint32_t)__shfl((int)len_l, (int)li, 64);
+            const uint64_t lo = (uint64_t)__shfl((unsigned long long)lo_l, (int)li, 64);
+            const uint8_t *__restrict__ src = a.prefix_blob + p0;
+            uint8_t *__restrict__ dst = a.out + lo;
+            const uint32_t head = min((uint32_t)(-(int32_t)(uint32_t)(uintptr_t)dst) & 3u, len);   // bytes before the first aligned dword
+            const uint32_t nd = (len - head) >> 2, tail = (len - head) & 3u;
+            for (uint32_t d = sub; d < nd; d += lanes) {
+                uint32_t w;
+                __builtin_memcpy(&w, src + head + 4u * d, 4);
+                *reinterpret_cast<uint32_t *>(dst + head + 4u * d) = w;
+            }
+            if (sub < head) dst[sub] = src[sub];
+            if (sub >= 4u && sub - 4u < tail) dst[head + 4u * nd + (sub - 4u)] = src[head + 4u * nd + (sub - 4u)];
+        }
     }
 }
 
@@ -1098,9 +1121,13 @@ bool gt_wide_applicable(const EmitArgs &a)
 hipError_t launch_copy_prefixes(const EmitArgs &a, int num_cus, hipStream_t stream)
 {
     if (a.n_variants == 0 || a.line_off == nullptr || a.prefix_blob == nullptr) return hipGetLastError();
-    const uint64_t blocks_needed = ((uint64_t)a.n_variants * 16ull + 255ull) / 256ull;
+    const uint64_t blocks_needed = ((uint64_t)a.n_variants + 255ull) / 256ull;   // a wave takes 64 lines per round, four waves per block
     const uint64_t pcap = (uint64_t)num_cus * 8ull;
-    hipLaunchKernelGGL(copy_prefixes_kernel, dim3((uint32_t)(blocks_needed < pcap ? blocks_needed : pcap)), dim3(256), 0, stream, a);
+    const uint64_t max_prefix = a.max_line_bytes - (4ull * a.kept_count + 1ull);
+    // lanes per line, ms for 1 M lines of 2 504 samples with 30 / 100 / 166-byte prefixes: 8 lanes 0.055 / 0.123 / 0.217, 16 lanes 0.076 /
+    // 0.117 / 0.162, 32 lanes - / 0.136 / 0.171, the wave - / - / 0.251 (the quarter-wave byte loop of the first version: 0.087 / - / 0.202)
+    const uint32_t shift = max_prefix <= 48ull ? 3u : 4u;
+    hipLaunchKernelGGL(copy_prefixes_kernel, dim3((uint32_t)(blocks_needed < pcap ? blocks_needed : pcap)), dim3(256), 0, stream, a, shift);
     return hipGetLastError();
 }
 
