@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--arms", nargs="+", default=["auto"])
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=3, help="launches per timing")
+    ap.add_argument("--gather", action="store_true", help="rows through a variant index list (every other record of a file twice as long)")
     ap.add_argument("--lines", type=int, default=0, metavar="PREFIX_BYTES",
                     help="full VCF body lines (pgenhip_emit_lines) with synthetic prefixes of about this many bytes instead of GT segments")
     args = ap.parse_args()
@@ -53,7 +54,8 @@ def main():
             eng.tune(KNOBS[kk], int(vv))
         arms.append((spec, KERNELS[name], eng))
     e0 = arms[0][2]
-    recs = e0.synth_records(v)
+    recs = e0.synth_records(2 * v if args.gather else v)
+    vidx = torch.arange(0, 2 * v, 2, dtype=torch.int32, device="cuda:0") + torch.randint(0, 2, (v,), dtype=torch.int32, device="cuda:0") if args.gather else None
     lines = None
     if args.lines:
         rng = np.random.default_rng(2)
@@ -70,9 +72,9 @@ def main():
 
     def launch(eng, kern):
         if lines is None:
-            eng.decode_emit(recs, v, out=out, kernel=kern)
+            eng.decode_emit(recs, v, out=out, kernel=kern, variant_idx=vidx)
         else:
-            eng.emit_lines(recs, v, lines[0], lines[1], lines[2], lines[3], out, kernel=kern)
+            eng.emit_lines(recs, v, lines[0], lines[1], lines[2], lines[3], out, kernel=kern, variant_idx=vidx)
 
     times = {spec: [] for spec, _, _ in arms}
     ref = None
