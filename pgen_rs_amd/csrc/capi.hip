@@ -274,8 +274,10 @@ static int dispatch_all_samples(pgenhip_ctx *ctx, const EmitArgs &a)
         // so that every 128-B line leaves whole: 0.68-0.71 of roofline from N = 100 to 1500 where the flat kernel had
         // 0.42-0.56, the pick kernel 0.31-0.62 and the row-item stream kernel 0.51-0.65 (profiles/r02_kernel_sweeps.md)
         LAUNCH_TRY(launch_gt_runs(a, t, ctx->num_cus, ctx->stream));
-    else if (gt_pick_applicable(a) && a.sample_count >= 400u && a.sample_count < 1400u)
-        // short rows that are gathered or padded (no contiguous runs): batches of rows through gt_pick.hip with the identity for a table
+    else if (gt_pick_applicable(a) && a.sample_count < 2000u)
+        // short rows that are gathered or padded (no contiguous runs): batches of rows through gt_pick.hip with the identity for a
+        // table, several rows per load instruction.  Gathered rows, fraction of roofline, pick / flat / row-item stream kernel:
+        // N = 64 0.46 / 0.28 / -, 300 0.49 / 0.31 / -, 1 399 0.58 / 0.40 / 0.52, 1 500 0.58 / 0.40 / 0.54, 2 504 0.59 / 0.41 / 0.68
         LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
     else if (gt_wide_applicable(a))
         LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));

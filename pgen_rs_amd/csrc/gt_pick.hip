@@ -127,9 +127,13 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
     const uint32_t R = a.record_size;
     const uint32_t S = p.row_bytes;
     const uint32_t B = p.batch_rows;
-    // the record's last piece is read pulled back into the record (R >= 16) and shifted into place when parked
-    const uint32_t piece_off = min(lane * 16u, R - 16u);
-    const uint32_t tail_shift = lane * 16u + 16u <= R ? 0u : min(lane * 16u - (R - 16u), 16u);
+    // Rows that are NOT one dense byte run (gathered / padded records) are fetched row by row, G = 64 / lanes_per_row rows per load
+    // instruction: lane -> (row `grp` of the instruction, 16-byte piece `piece` of its record); pitch = lanes_per_row * 16.
+    // The record's last piece is read pulled back into the record (R >= 16) and shifted into place when parked.
+    const uint32_t lpr = p.pitch >> 4;                                  // lanes per row: pieces rounded up to a power of two (not PACKED)
+    const uint32_t grp = lane / lpr, piece = lane & (lpr - 1u), G = 64u / lpr;
+    const uint32_t piece_off = min(piece * 16u, R - 16u);
+    const uint32_t tail_shift = piece * 16u + 16u <= R ? 0u : min(piece * 16u - (R - 16u), 16u);
 
     const uint32_t batch_step = gridDim.x * kWaves;
     uint32_t bi = blockIdx.x * kWaves + wave;
@@ -159,13 +163,19 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
             }
             return;
         }
+        // where the batch's rows lie: lane l looks up row row0 + l once (B <= 64), every lane then takes its row's with a shuffle
+        uint64_t place = 0ull;
+        {
+            const uint64_t row = min(row0 + (uint64_t)lane, (uint64_t)a.n_variants - 1ull);  // rows past the end re-load the last row
+            place = HAS_VIDX ? (uint64_t)(gathered_record(a, row) - a.records) : row * a.record_stride;
+        }
 #pragma unroll
         for (int i = 0; i < kMaxBatchRows; i++) {
             buf[i] = v4u{0u, 0u, 0u, 0u};
-            if ((uint32_t)i < B) {
-                const uint64_t row = min(row0 + (uint64_t)i, (uint64_t)a.n_variants - 1ull);  // rows past the end re-load the last row
-                const uint8_t *__restrict__ rec = HAS_VIDX ? gathered_record(a, row) : a.records + row * a.record_stride;
-                if (lane < p.pieces) __builtin_memcpy(&buf[i], rec + piece_off, 16);
+            if ((uint32_t)i * G < B) {
+                const uint32_t bi_row = (uint32_t)i * G + grp;           // row of the batch this lane works for in instruction i
+                const uint64_t off = (uint64_t)__shfl((unsigned long long)place, (int)min(bi_row, 63u), 64);
+                if (bi_row < B && piece < p.pieces) __builtin_memcpy(&buf[i], a.records + off + piece_off, 16);
             }
         }
     };
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
         }
 #pragma unroll
         for (int i = 0; i < kMaxBatchRows; i++) {
-            if (!packed && (uint32_t)i < B && lane < p.pieces) {
+            if (!packed && (uint32_t)i * G + grp < B && piece < p.pieces) {
                 v4u x = buf[i];
                 if (tail_shift != 0u) {
                     uint64_t lo = (uint64_t)x.x | ((uint64_t)x.y << 32), hi = (uint64_t)x.z | ((uint64_t)x.w << 32);
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
                     else { lo = (lo >> sh8) | (hi << (64u - sh8)); hi >>= sh8; }
                     x = v4u{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
                 }
-                *reinterpret_cast<v4u *>(stage + (uint32_t)i * p.pitch + lane * 16u) = x;
+                *reinterpret_cast<v4u *>(stage + ((uint32_t)i * G + grp) * p.pitch + piece * 16u) = x;
             }
         }
         const uint64_t text_off_cur = text_off;   // (this batch's; load_batch below overwrites it with the next batch's)
@@ -333,7 +343,13 @@ hipError_t launch_gt_pick(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
         if (b > kMaxPackedRows) b = kMaxPackedRows;
         if (b > (kStageBytes - 16u) / p.pitch) b = (kStageBytes - 16u) / p.pitch;  // 15 bytes of misalignment + B * R <= 8 192: >= 7 rows, <= 8 loads
     } else {
-        if (b > (uint32_t)kMaxBatchRows) b = (uint32_t)kMaxBatchRows;
+        // row-by-row loads, G rows per instruction: lanes per row = the record's pieces rounded up to a power of two
+        uint32_t lpr = 1u;
+        while (lpr < p.pieces) lpr <<= 1;
+        p.pitch = lpr * 16u;
+        const uint32_t rows_per_load = 64u / lpr;
+        if (b > (uint32_t)kMaxBatchRows * rows_per_load) b = (uint32_t)kMaxBatchRows * rows_per_load;
+        if (b > kMaxPackedRows) b = kMaxPackedRows;
         if (b > kStageBytes / p.pitch) b = kStageBytes / p.pitch;  // >= 8 (pitch <= 1024)
     }
     p.batch_rows = b;
