@@ -20,7 +20,7 @@ DENSITIES = [None, 0.9, 0.5, 0.1, 0.01, 0.001]          # None = all samples
 TARGET_BYTES = 8e9
 
 
-def measure(n, frac, lines):
+def measure(n, frac, lines, gather=False):
     kept = None
     if frac is not None:
         k = int(n * frac)
@@ -30,7 +30,8 @@ def measure(n, frac, lines):
     with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
         per_row = eng.record_size + eng.gt_row_bytes + (2 * lines if lines else 0)
         v = int(max(1000, min(TARGET_BYTES // per_row, 60_000_000)))
-        recs = eng.synth_records(v)
+        recs = eng.synth_records(2 * v if gather else v)
+        vidx = (torch.arange(0, 2 * v, 2, dtype=torch.int32, device="cuda:0") + torch.randint(0, 2, (v,), dtype=torch.int32, device="cuda:0")) if gather else None
         if lines:
             rng = np.random.default_rng(2)
             plen = rng.integers(max(2, lines - 8), lines + 9, size=v).astype(np.int64)
@@ -42,13 +43,13 @@ def measure(n, frac, lines):
             alg = v * eng.record_size + 2 * int(poff[-1]) + v * eng.gt_row_bytes
 
             def launch():
-                eng.emit_lines(recs, v, blob, poff_t, loff_t, int(plen.max()), out)
+                eng.emit_lines(recs, v, blob, poff_t, loff_t, int(plen.max()), out, variant_idx=vidx)
         else:
             out = torch.empty(v * eng.gt_row_bytes, dtype=torch.uint8, device="cuda:0")
             alg = v * (eng.record_size + eng.gt_row_bytes)
 
             def launch():
-                eng.decode_emit(recs, v, out=out)
+                eng.decode_emit(recs, v, out=out, variant_idx=vidx)
         launch()
         torch.cuda.synchronize()
         ts = []
@@ -64,14 +65,14 @@ def measure(n, frac, lines):
     return alg / (statistics.median(ts) * 1e-3) / 8e12
 
 
-def table(lines):
+def table(lines, gather=False):
     head = "| N \\ kept | " + " | ".join("all" if d is None else f"{d * 100:g} %" for d in DENSITIES) + " |"
     print(head)
     print("|" + "---|" * (len(DENSITIES) + 1))
     for n in SAMPLES:
         cells = []
         for d in DENSITIES:
-            f = measure(n, d, lines)
+            f = measure(n, d, lines, gather)
             cells.append("—" if f is None else f"{f:.2f}")
             torch.cuda.empty_cache()
         print(f"| {n} | " + " | ".join(cells) + " |", flush=True)
@@ -84,3 +85,5 @@ if __name__ == "__main__":
     table(30)
     print("\n## Full lines, prefixes of 158-174 bytes (the reference's basic1.pvar rows: 132-248)\n")
     table(166)
+    print("\n## GT segments, GATHERED rows (variant index list: every other record of a file twice as long) — an API path, the CLI packs its records\n")
+    table(0, gather=True)
