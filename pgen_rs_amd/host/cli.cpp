@@ -30,7 +30,7 @@ const char *kUsage =
     "  help    Print this message\n\n"
     "query  <PFILE_PREFIX> -f, --fstring <QUERY_FSTRING> [-i, --include <QUERY>] [-s, --samples]\n"
     "filter <PFILE_PREFIX> [--include-var <VAR_QUERY>] [--include-sam <SAM_QUERY>] [-o, --out <OUT_FILE>]\n"
-    "       [--gpus <N>] [--shards <S>] [--block-mib <M>] [--write-threads <T>] [--stats] [--dry-run]\n";
+    "       [--gpus <N>] [--shards <S>] [--block-mib <M>] [--write-threads <T>] [--read-threads <T>] [--stats] [--dry-run]\n";
 
 [[noreturn]] void usage_error(const std::string &msg)
 {
@@ -157,7 +157,7 @@ int main(int argc, char **argv)
             return 0;
         }
         if (cmd == "filter") {  // src/main.rs:114-124
-            Args a = parse(argc, argv, 2, {{"include-var", 0}, {"include-sam", 0}, {"out", 'o'}, {"gpus", 0}, {"shards", 0}, {"block-mib", 0}, {"write-threads", 0}},
+            Args a = parse(argc, argv, 2, {{"include-var", 0}, {"include-sam", 0}, {"out", 'o'}, {"gpus", 0}, {"shards", 0}, {"block-mib", 0}, {"write-threads", 0}, {"read-threads", 0}},
                            {{"stats", 0}, {"dry-run", 0}});
             if (a.positional.size() != 1) usage_error("the following required arguments were not provided: <PFILE_PREFIX>");
             const Pfile pfile = Pfile::from_prefix(a.positional[0]);
@@ -190,6 +190,7 @@ int main(int argc, char **argv)
             if (auto g = a.get("gpus")) opt.n_gpus = std::max(1, std::atoi(g->c_str()));
             if (auto sh = a.get("shards")) opt.n_shards = std::max(1, std::atoi(sh->c_str()));
             if (auto w = a.get("write-threads")) opt.write_threads = std::max(1, std::atoi(w->c_str()));
+            if (auto w = a.get("read-threads")) opt.read_threads = std::max(1, std::atoi(w->c_str()));
             if (auto m = a.get("block-mib")) opt.block_text_bytes = (uint64_t)std::max(1, std::atoi(m->c_str())) << 20;
             const OutputStats st = pfile.output_vcf(a.get("include-sam"), a.get("include-var"), out_file, opt);  // :123
             if (a.has("stats")) {

@@ -456,9 +456,10 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
             int pfd = open(pgen.c_str(), O_RDONLY);  // :149 (unbuffered on purpose, :150-152)
             if (pfd < 0) throw PfileError("open " + pgen + ": " + std::strerror(errno));
             FdGuard pg{pfd};
-            // variants per block: bounded by the text budget
+            // variants per block: bounded by the text budget — and by the same budget of RECORD bytes, so that a run that keeps few
+            // samples (little text per record) still moves in several blocks and its file reads overlap the copies and the kernel
             const uint64_t max_line = max_prefix + 4ull * K + 1ull;
-            const uint64_t bv = std::max<uint64_t>(1, std::min<uint64_t>(opt.block_text_bytes / max_line, end - begin));
+            const uint64_t bv = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(opt.block_text_bytes / max_line, opt.block_text_bytes / std::max<uint32_t>(R, 1u)), end - begin));
             const size_t rec_bytes = (size_t)(bv * R), blob_bytes = (size_t)(bv * max_prefix), text_bytes = (size_t)(bv * max_line);
             const size_t off_bytes = (size_t)(2 * (bv + 1) * sizeof(uint64_t));
             const size_t n_blocks = (end - begin + (size_t)bv - 1) / (size_t)bv;
@@ -581,7 +582,32 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                     while (j + run < nv && var_idx_rcds[b0 + j + run].first == var_idx_rcds[b0 + j].first + run &&
                            record_offset(var_idx_rcds[b0 + j + run].first) == record_offset(var_idx_rcds[b0 + j].first) + run * (uint64_t)R)
                         run++;
-                    pread_exact(pfd, h_rec + j * R, run * (size_t)R, record_offset(var_idx_rcds[b0 + j].first), pgen);
+                    // (a long run is read by a few threads at once: one thread copies ~2-3 GB/s out of the page cache)
+                    const size_t run_bytes = run * (size_t)R;
+                    const uint64_t run_off = record_offset(var_idx_rcds[b0 + j].first);
+                    const unsigned n_readers = run_bytes >= (64u << 20) ? (unsigned)std::max(1, opt.read_threads) : 1u;
+                    if (n_readers <= 1) {
+                        pread_exact(pfd, h_rec + j * R, run_bytes, run_off, pgen);
+                    } else {
+                        std::vector<std::thread> rs;
+                        std::string rerr;
+                        std::mutex rmu;
+                        const size_t slice = (run_bytes + n_readers - 1) / n_readers;
+                        for (unsigned t = 0; t < n_readers; t++) {
+                            const size_t lo = std::min(run_bytes, (size_t)t * slice), hi = std::min(run_bytes, lo + slice);
+                            if (lo == hi) continue;
+                            rs.emplace_back([&, lo, hi] {
+                                try {
+                                    pread_exact(pfd, h_rec + j * R + lo, hi - lo, run_off + lo, pgen);
+                                } catch (const std::exception &e) {
+                                    std::lock_guard<std::mutex> lk(rmu);
+                                    rerr = e.what();
+                                }
+                            });
+                        }
+                        for (auto &t : rs) t.join();
+                        if (!rerr.empty()) throw PfileError(rerr);
+                    }
                     j += run;
                 }
                 // :157-161 joined once per variant: col '\t' col '\t' ... "GT"
