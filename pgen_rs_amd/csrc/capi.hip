@@ -292,8 +292,10 @@ static int dispatch_all_samples(pgenhip_ctx *ctx, const EmitArgs &a)
 static int dispatch_all_samples_lines(pgenhip_ctx *ctx, const EmitArgs &a)
 {
     const Tuning &t = ctx->tune;
-    if (gt_wide_lines_applicable(a)) {
-        // rows of >= 4 KiB: the work-queue stream kernel writes the GT segments in place behind their prefixes (+ a small prefix copy)
+    if (gt_wide_lines_applicable(a) && a.sample_count >= 1400u) {
+        // long rows: the work-queue stream kernel writes the GT segments in place behind their prefixes (+ a small prefix copy).
+        // From N = 1 400: at N = 1 024 / 1 200 it runs at 0.45 / 0.49 of roofline against 0.48-0.51 for the two kernels below, at
+        // N = 1 500 / 1 900 at 0.56 / 0.60 against 0.49-0.55 (profiles/r02_kernel_sweeps.md)
         LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
     } else if (gt_lineruns_applicable(a) && (gt_lineruns_rows(a) >= 7u || a.sample_count >= 500u)) {
         // short rows, dense records: runs of whole lines (prefix + GT + '\n') assembled in LDS and stored as whole 128-B lines.
