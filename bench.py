@@ -15,15 +15,22 @@ an output buffer in HBM that holds as many variants as fit beside the records (o
 whole range fits — configs[2] does: 12.5 GB in, 200 GB out — otherwise a few launches that re-use the buffer,
 as a D2H pipeline would).
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own ranks: the parent — which
+never imports torch or touches a GPU — runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+CHILD process, relays its output and returns its exit code (never a re-exec).
+
 One JSON line on stdout (rank 0).  Besides the contract's keys:
   `roofline`       HBM; algorithmic bytes (R + 4K + 1 per variant) / hipEvent time on the
                    kernel's stream; per-step event pairs give min / median / max (the output buffer's
                    physical placement moves a launch by 5-9 % between processes, DESIGN.md §4);
-                   `traffic` from the committed PMC passes of the same shape (profiles/r02_*/pmc_summary.json)
+                   `traffic` from the committed PMC passes of the same shape (profiles/r0*/pmc_summary.json, latest round first)
   `cpu_baseline`   the oracle's literal restatement of the reference loop, 1 core, same N, bounded V
   `host_delivered` PCIe-inclusive rate (pinned host records -> H2D || kernel || D2H -> pinned host text),
                    measured OUTSIDE the timed region; it is never `value`
   `self_check`     structure of every row + a torch re-encode round trip on sampled rows (no oracle here)
+  `secondary`      the other BASELINE shapes, a few steps each AFTER the headline and outside its timed region:
+                   N = 1: `c5shard` (north_star's ">= 50 % of the HBM-read roofline on the 2-bit unpack" lives here:
+                   `read_only_frac`), `chr22`, `basic2`;  N > 1: `c5` (configs[4]) on the ranks' resident c4 records
 """
 from __future__ import annotations
 
@@ -243,7 +250,7 @@ def self_check(torch, recs, out, v_rows: int, n: int, r: int, k: int, kept, row_
 def load_traffic(v_launch: int, n: int, k: int):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     runs, KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md) — only if the shape matches exactly."""
-    for p in sorted((REPO_ROOT / "profiles").glob("r02_*/pmc_summary.json")):
+    for p in sorted((REPO_ROOT / "profiles").glob("r0*/pmc_summary.json"), reverse=True):  # the latest round's passes first
         try:
             t = json.loads(p.read_text())
         except (OSError, ValueError):
@@ -252,6 +259,110 @@ def load_traffic(v_launch: int, n: int, k: int):
         if sh.get("variants_per_launch") == v_launch and sh.get("samples") == n and sh.get("kept") == k and t.get("hbm_bytes_per_launch"):
             return t["hbm_bytes_per_launch"], f"{p.relative_to(REPO_ROOT)}: {t.get('note', '')}"
     return None, None
+
+
+def self_launch(argv: list[str], n_ranks: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child `torch.distributed.run` job.  Called
+    before torch is imported — this process never initialises a GPU (a process that has must not exec another program
+    on this pool) — and it spawns, relays and returns the child's exit code; it never re-execs itself."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between the ranks needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, cwd=str(REPO_ROOT))
+    assert child.stdout is not None
+    for ln in child.stdout:  # rank 0's JSON line (and anything else the ranks print) goes straight through
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return child.wait()
+
+
+def time_steps(torch, dist, eng, recs, out, v: int, v_launch: int, r: int, steps: int, warmup: int, kernel: int, dev, world: int) -> dict:
+    """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides.  Wall clock for
+    `value`; the ctx's hipEvent pair on the kernels' stream for the roofline; one torch event pair per step for the spread."""
+
+    def step() -> None:
+        for b0 in range(0, v, v_launch):
+            nb = min(v_launch, v - b0)
+            eng.decode_emit(recs, nb, out=out, kernel=kernel, records_offset=b0 * r)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    # per-step event pairs on the stream the kernels run on (the ctx is bound to torch's current stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    eng.timer_start()                      # hipEvent pair of the ctx, same stream, around the whole timed region
+    for e0, e1 in evs:
+        e0.record()
+        step()
+        e1.record()
+    event_ms = eng.timer_stop()            # records + synchronises the stop event
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"dt": dt, "event_ms": event_ms, "step_ms": [e0.elapsed_time(e1) for e0, e1 in evs]}
+
+
+def launch_plan(torch, dev, v: int, row_bytes: int, share: int, max_launch_variants: int):
+    """As many output rows as fit beside what is already resident, in even launches."""
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    budget = max(free_b // share - (6 << 30), row_bytes)
+    v_launch = max(1, min(v, budget // row_bytes)) if v else 0
+    if max_launch_variants:
+        v_launch = min(v_launch, max_launch_variants)
+    n_launch = (v + v_launch - 1) // v_launch if v else 0
+    if n_launch:
+        v_launch = (v + n_launch - 1) // n_launch  # even launches
+    return v_launch, n_launch
+
+
+def secondary_one(torch, pgen_rs_amd, name: str, dev_index: int, steps: int, warmup: int, hwe: bool) -> dict:
+    """One of the other BASELINE shapes on this GPU, a few steps, event-timed on the kernels' stream; outside the
+    headline's timed region (its buffers are freed first)."""
+    from pgen_rs_amd.synth import keep_indices
+
+    dev = torch.device("cuda", dev_index)
+    v, n, keep_mod, desc = CONFIGS[name]
+    kept = keep_indices(n, modulus=keep_mod) if keep_mod else None
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=dev_index) as eng:
+        k, r, row_bytes = eng.kept_count, eng.record_size, eng.gt_row_bytes
+        recs = eng.synth_records(v, seed=SEED_DATA, hwe=hwe)
+        torch.cuda.synchronize(dev)
+        v_launch, n_launch = launch_plan(torch, dev, v, row_bytes, 1, 0)
+        out = torch.empty(v_launch * row_bytes, dtype=torch.uint8, device=dev)
+        t = time_steps(torch, None, eng, recs, out, v, v_launch, r, steps, warmup, 0, dev, 1)
+        check = self_check(torch, recs[(n_launch - 1) * v_launch * r :], out, v - (n_launch - 1) * v_launch, n, r, k, kept, row_bytes)
+        ms = t["event_ms"] / steps
+        alg = v * (r + 4 * k + 1)
+        res = {
+            "workload": f"{name}: {desc}",
+            "variants": v, "samples": n, "kept_samples": k, "steps": steps, "launches_per_step": n_launch,
+            "ms_per_step": ms,
+            "step_ms": {"min": min(t["step_ms"]), "median": statistics.median(t["step_ms"]), "max": max(t["step_ms"])},
+            "genotypes_per_s": v * n / (ms * 1e-3),
+            "algorithmic_bytes_per_step": alg,
+            "achieved_GBps": alg / (ms * 1e-3) / 1e9,
+            "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "read_only_frac": v * r / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "self_check_ok": bool(check["ok"]),
+        }
+        del recs, out
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    return res
 
 
 def main() -> int:
@@ -270,11 +381,15 @@ def main() -> int:
     ap.add_argument("--max-launch-variants", type=int, default=0, help="cap on variants per launch (0 = as many as fit in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-delivered", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (the other BASELINE shapes after the headline)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --dist-backend gloo) so the N>1 code path can run on a 1-GPU box")
     ap.add_argument("--kernel", type=int, default=0, help="PGENHIP_KERNEL_* override for A/B runs (0 = automatic, the measured default)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(sys.argv[1:], args.gpus)   # before `import torch`: the parent never touches a GPU
 
     import torch
     import torch.distributed as dist
@@ -286,8 +401,6 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -305,13 +418,13 @@ def main() -> int:
 
     cfg_name = args.config or ("c3" if world == 1 else "c4")
     v_total, n, keep_mod, cfg_desc = CONFIGS[cfg_name]
-    custom = False
+    custom = custom_geometry = False
     if args.variants is not None and args.variants != v_total:
         v_total, custom = args.variants, True
     if args.samples is not None and args.samples != n:
-        n, custom = args.samples, True
+        n, custom, custom_geometry = args.samples, True, True
     if args.keep_modulus is not None and args.keep_modulus != keep_mod:
-        keep_mod, custom = args.keep_modulus, True
+        keep_mod, custom, custom_geometry = args.keep_modulus, True, True
 
     kept = None
     if keep_mod:
@@ -319,6 +432,7 @@ def main() -> int:
 
         kept = keep_indices(n, modulus=keep_mod)
 
+    hwe = args.distribution == "hwe"
     eng = pgen_rs_amd.GtEngine(n, kept_idx=kept, device=local_rank)
     k, r, row_bytes = eng.kept_count, eng.record_size, eng.gt_row_bytes
     begin, end = shard_range(v_total, world, rank)  # this rank's contiguous slice of the kept-variant list
@@ -328,51 +442,19 @@ def main() -> int:
     # allocations so that it does not run beside the driver unmapping 200 GB of freed output buffer)
     hd = None
     if world == 1 and rank == 0 and not args.no_host_delivered and v > 0:
-        hd = host_delivered(torch, pgen_rs_amd, local_rank, n, kept, v, hwe=args.distribution == "hwe")
+        hd = host_delivered(torch, pgen_rs_amd, local_rank, n, kept, v, hwe=hwe)
         torch.cuda.synchronize(dev)
         torch.cuda.empty_cache()
 
     # the rank's records, resident before the timed region; then as many output rows as fit beside them
-    recs = eng.synth_records(v, first_variant=begin, seed=SEED_DATA, hwe=args.distribution == "hwe")
+    recs = eng.synth_records(v, first_variant=begin, seed=SEED_DATA, hwe=hwe)
     torch.cuda.synchronize(dev)
-    free_b, _total_b = torch.cuda.mem_get_info(dev)
     share = world if args.all_ranks_on_device0 else 1
-    budget = max(free_b // share - (6 << 30), row_bytes)
-    v_launch = max(1, min(v, budget // row_bytes)) if v else 0
-    if args.max_launch_variants:
-        v_launch = min(v_launch, args.max_launch_variants)
-    n_launch = (v + v_launch - 1) // v_launch if v else 0
-    if n_launch:
-        v_launch = (v + n_launch - 1) // n_launch  # even launches
+    v_launch, n_launch = launch_plan(torch, dev, v, row_bytes, share, args.max_launch_variants)
     out = torch.empty(max(v_launch, 1) * row_bytes, dtype=torch.uint8, device=dev)
 
-    def step() -> None:
-        for b0 in range(0, v, v_launch):
-            nb = min(v_launch, v - b0)
-            eng.decode_emit(recs, nb, out=out, kernel=args.kernel, records_offset=b0 * r)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    # per-step event pairs on the stream the kernels run on (the ctx is bound to torch's current stream)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    eng.timer_start()                      # hipEvent pair of the ctx, same stream, around the whole timed region
-    for e0, e1 in evs:
-        e0.record()
-        step()
-        e1.record()
-    event_ms = eng.timer_stop()            # records + synchronises the stop event
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-
-    step_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    t = time_steps(torch, dist, eng, recs, out, v, v_launch, r, args.steps, args.warmup, args.kernel, dev, world)
+    dt, event_ms, step_ms = t["dt"], t["event_ms"], t["step_ms"]
     t_all = torch.tensor([dt, event_ms, max(step_ms), -min(step_ms)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
@@ -382,6 +464,53 @@ def main() -> int:
     if rank == 0 and v > 0:
         last_nb = v - (n_launch - 1) * v_launch  # rows the last launch of a step left in `out`
         check = self_check(torch, recs[(n_launch - 1) * v_launch * r :], out, last_nb, n, r, k, kept, row_bytes)
+
+    # ---- secondary: the other BASELINE shapes, after the headline and outside its timed region ------------------
+    secondary = None
+    if not args.no_secondary and not custom_geometry and args.kernel == 0:  # (a custom VARIANT count keeps it: tests rehearse it small)
+        sec_steps = max(3, min(args.steps, 5))
+        if world == 1 and cfg_name == "c3":
+            # one GPU: north_star's second target (>= 50 % of the HBM-READ roofline on the unpack) is physical only where few samples are
+            # kept: configs[4]'s per-GPU shard; plus configs[1]'s block and the reference's own dataset shape
+            del out, recs
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
+            secondary = {}
+            for name, st in (("c5shard", sec_steps), ("chr22", sec_steps), ("basic2", 4 * sec_steps)):
+                secondary[name] = secondary_one(torch, pgen_rs_amd, name, local_rank, st, 2, hwe)
+            recs = out = None
+        elif world > 1 and cfg_name == "c4" and v > 0:
+            # several GPUs: configs[4] = the same 1 M x 500 k records with the 1 % keep mask — every rank's shard is already resident
+            from pgen_rs_amd.synth import keep_indices
+
+            del out
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
+            kept5 = keep_indices(n, modulus=CONFIGS["c5"][2])
+            with pgen_rs_amd.GtEngine(n, kept_idx=kept5, device=local_rank) as e5:
+                k5, row5 = e5.kept_count, e5.gt_row_bytes
+                vl5, nl5 = launch_plan(torch, dev, v, row5, share, 0)
+                out5 = torch.empty(vl5 * row5, dtype=torch.uint8, device=dev)
+                t5 = time_steps(torch, dist, e5, recs, out5, v, vl5, r, sec_steps, 2, 0, dev, world)
+                t5_all = torch.tensor([t5["dt"], t5["event_ms"]], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t5_all, op=dist.ReduceOp.MAX)
+                ok5 = True
+                if rank == 0:
+                    ok5 = self_check(torch, recs[(nl5 - 1) * vl5 * r :], out5, v - (nl5 - 1) * vl5, n, r, k5, kept5, row5)["ok"]
+                del out5
+            if rank == 0:
+                dt5, ev5 = float(t5_all[0]), float(t5_all[1])
+                alg5 = v * (r + 4 * k5 + 1)
+                secondary = {"c5": {
+                    "workload": f"c5: {CONFIGS['c5'][3]}" + (f" (custom: {v_total} variants)" if custom else "") +
+                                f"; rank r decodes its contiguous 1/{world} of the variants, the records the c4 headline left resident",
+                    "variants_total": v_total, "samples": n, "kept_samples": k5, "steps": sec_steps, "launches_per_step": nl5,
+                    "value": v_total * n * sec_steps / dt5, "unit": "genotypes/s", "ms_per_step": dt5 / sec_steps * 1e3,
+                    "kernel_ms_per_step_max_over_ranks": ev5 / sec_steps,
+                    "frac": alg5 / (ev5 / sec_steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "read_only_frac": v * r / (ev5 / sec_steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "self_check_ok": bool(ok5),
+                }}
 
     if rank == 0:
         genotypes_per_step = v_total * n                       # every 2-bit code of every record is decoded
@@ -446,6 +575,8 @@ def main() -> int:
             },
             "self_check": check,
         }
+        if secondary is not None:
+            line["secondary"] = secondary
         if hd is not None:
             line["host_delivered"] = hd
         if world == 1 and not args.no_cpu_baseline:

@@ -26,7 +26,13 @@
  * takes its own block of work-queue counters from a ring of
  * PGENHIP_LAUNCHES_IN_FLIGHT, so at most that many launches of ONE ctx may be
  * in flight at once (a host that keeps more queued must pgenhip_wait in
- * between).  The kernels leave their counter block zeroed; after a launch
+ * between).  The scratch of the two-pass path (sparse keeps on long
+ * records) is sliced the same way: each launch in flight has its own slice.
+ * A launch captured into a HIP graph keeps the ring slot it was captured
+ * with, so a REPLAY of that graph must not overlap other launches of the same
+ * ctx (they come round to its slot every PGENHIP_LAUNCHES_IN_FLIGHT
+ * launches): replay on the stream the ctx launches on, or give the graph a
+ * ctx of its own.  The kernels leave their counter block zeroed; after a launch
  * that FAILED (any negative status from a launch call) the ctx re-zeroes the
  * whole ring in stream order before its next launch.  A kernel that faults
  * on the device takes the process down like any HIP fault; nothing is
@@ -114,7 +120,10 @@ int pgenhip_vw_parse_header(const uint8_t header[12], pgenhip_vw_header *out);
  * (index_len of them); outputs are HOST arrays of variant_count entries: the record's type (4- or 8-bit value),
  * its length and its byte offset in the file (block offset + lengths of the block's earlier records).
  * PGENHIP_ERR_BAD_INDEX: table truncated, block offsets not strictly ascending (:160-165), a block's records
- * run into the next block, or the first record starts inside the tables. */
+ * run into the next block, the first record starts inside the tables, or offsets overflow 64 bits.
+ * PGENHIP_ERR_BAD_ARG: *h is not what pgenhip_vw_parse_header produces — record_type_bits not 4 / 8, record_length_bytes
+ * not 1..4, or block_count / variant_records_offset that do not follow from variant_count and those widths (the walk
+ * recomputes them; nothing derived is trusted). */
 int pgenhip_vw_walk_index(const pgenhip_vw_header *h, const uint8_t *index, uint64_t index_len,
                           uint8_t *record_type, uint32_t *record_len, uint64_t *record_off);
 /* The selected variants (variant_idx[0..n), or the first n when NULL) must all be plain 2-bit records:
@@ -156,7 +165,7 @@ uint64_t pgenhip_gt_row_bytes(const pgenhip_ctx *ctx);
 #define PGENHIP_KERNEL_SCAN 3u   /* kept subset on long records: per-segment rank->sample table pick (N >= 61) */
 #define PGENHIP_KERNEL_WIDE 4u   /* dense all-samples, wide LDS-staged record loads, one row piece per item (N >= 1024) */
 /* 5u was round 1's stream-span kernel (measured level with WIDE, removed) */
-#define PGENHIP_KERNEL_PICK 6u   /* kept subset on short records (61 <= N <= 4096, K >= 4, dense pitch): output-driven pick through the kept list */
+#define PGENHIP_KERNEL_PICK 6u   /* kept subset on short records (61 <= N <= 4096, K >= 1, dense pitch): output-driven pick through the kept list */
 #define PGENHIP_KERNEL_RUNS 7u   /* dense all-samples on SHORT rows (8 <= N <= ~2000, dense records, no gather): runs of rows as one work item */
 #define PGENHIP_KERNEL_MASK 0xFu
 

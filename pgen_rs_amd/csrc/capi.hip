@@ -26,8 +26,9 @@ struct pgenhip_ctx {
     uint32_t *d_kept = nullptr;
     uint32_t *d_seg_rank = nullptr;    // segment kernels: kept samples before each segment
     uint32_t max_seg_count = 0;        // segment kernels: most kept samples in one segment
-    uint8_t *d_compact = nullptr;      // two-pass path for sparse keeps on long records: compact records of one chunk of rows
-    size_t compact_bytes = 0;
+    uint8_t *d_compact = nullptr;      // two-pass path for sparse keeps on long records: compact records of one chunk of rows,
+    size_t compact_bytes = 0;          // one slice of compact_bytes per launch in flight (the slice follows the launch's counter block)
+    uint32_t launch_slot = 0;          // ring slot of the launch being queued (claim_counters)
     uint64_t *d_work = nullptr;        // stream kernel: ring of PGENHIP_LAUNCHES_IN_FLIGHT counter blocks (8 work-queue heads 128 B apart + an exit counter)
     uint32_t launch_seq = 0;           // next counter block of the ring
     bool work_dirty = false;           // a launch failed: counters may be non-zero, re-zero the ring before the next launch
@@ -78,6 +79,10 @@ bool two_pass_shape(uint32_t sample_count, uint32_t kept_count)
 
 constexpr size_t kWorkBlockBytes = (kMaxQueueRanges + 1u) * 128u;  // the heads 128 B apart + the exit counter
 constexpr size_t kWorkBlockWords = kWorkBlockBytes / sizeof(uint64_t);
+// Two-pass path: every launch in flight has its own slice of compact-record scratch, like its own counter block (launches of one
+// ctx on different streams may overlap: include/pgen_hip.h, "Streams").  A slice holds one chunk of rows between the two passes;
+// a chunk stays in the 256-MiB Infinity Cache, so a smaller one costs only its two extra kernel launches.
+constexpr size_t kCompactSliceBytes = 32u << 20;
 
 }  // namespace
 
@@ -156,12 +161,12 @@ int pgenhip_create(pgenhip_ctx **out, int device_ordinal, uint32_t sample_count,
             }
             if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_seg_rank), seg_rank.size() * sizeof(uint32_t))) != hipSuccess) { rc = fail_hip(e, "hipMalloc(segment ranks)"); break; }
             if ((e = hipMemcpy(ctx->d_seg_rank, seg_rank.data(), seg_rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) { rc = fail_hip(e, "hipMemcpy(segment ranks)"); break; }
-            // two-pass path (sparse keeps on long records): a fixed 64-MiB scratch for the compact records of one chunk of rows (config
-            // 5's per-GPU shard, 125 000 rows x 1 235 bytes, is three chunks: measured 1 % ahead of one 154-MB chunk — the scratch
-            // stays in the 256-MiB Infinity Cache between the two passes); allocated here so that no launch ever allocates
+            // two-pass path (sparse keeps on long records): scratch for the compact records of one chunk of rows per launch in flight
+            // (config 5's per-GPU shard, 125 000 rows x 1 250 bytes, is five chunks; a chunk stays in the 256-MiB Infinity Cache
+            // between the two passes); allocated here so that no launch ever allocates
             if (two_pass_shape(sample_count, kept_count)) {
-                ctx->compact_bytes = 64u << 20;
-                if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_compact), ctx->compact_bytes)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(compact records)"); break; }
+                ctx->compact_bytes = kCompactSliceBytes;
+                if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->d_compact), PGENHIP_LAUNCHES_IN_FLIGHT * ctx->compact_bytes)) != hipSuccess) { rc = fail_hip(e, "hipMalloc(compact records)"); break; }
             }
         }
     } while (0);
@@ -244,7 +249,8 @@ static int claim_counters(pgenhip_ctx *ctx, EmitArgs &a)
         HIP_TRY(hipMemsetAsync(ctx->d_work, 0, PGENHIP_LAUNCHES_IN_FLIGHT * kWorkBlockBytes, ctx->stream));
         ctx->work_dirty = false;
     }
-    a.work_counters = ctx->d_work + (size_t)(ctx->launch_seq++ % PGENHIP_LAUNCHES_IN_FLIGHT) * kWorkBlockWords;
+    ctx->launch_slot = ctx->launch_seq++ % PGENHIP_LAUNCHES_IN_FLIGHT;
+    a.work_counters = ctx->d_work + (size_t)ctx->launch_slot * kWorkBlockWords;
     return PGENHIP_OK;
 }
 
@@ -326,6 +332,7 @@ static bool two_pass(const pgenhip_ctx *ctx, const EmitArgs &a)
 static int dispatch_two_pass(pgenhip_ctx *ctx, const EmitArgs &a, const ScanArgs &sc)
 {
     const uint32_t rc_bytes = (a.kept_count + 3u) / 4u;
+    uint8_t *const scratch = ctx->d_compact + (size_t)ctx->launch_slot * ctx->compact_bytes;  // this launch's own slice
     uint64_t chunk_rows = std::max<uint64_t>(1ull, ctx->compact_bytes / rc_bytes);
     if (ctx->tune.scan_chunk_rows > 0) chunk_rows = std::min<uint64_t>(chunk_rows, (uint64_t)ctx->tune.scan_chunk_rows);
     for (uint64_t row0 = 0; row0 < a.n_variants; row0 += chunk_rows) {
@@ -335,14 +342,14 @@ static int dispatch_two_pass(pgenhip_ctx *ctx, const EmitArgs &a, const ScanArgs
         else if (a.variant_idx) c.variant_idx = a.variant_idx + row0;
         else c.records = a.records + row0 * a.record_stride;
         c.n_variants = n;
-        c.out = ctx->d_compact;
+        c.out = scratch;
         c.out_stride = rc_bytes;
         c.prefix_blob = nullptr;
         c.prefix_off = nullptr;
         c.line_off = nullptr;
         LAUNCH_TRY(launch_gt_scan(c, sc, ctx->tune, ctx->num_cus, ctx->stream, true));
         EmitArgs d = a;  // pass 2: a block of n mode-0x02 records of K samples, all of them kept
-        d.records = ctx->d_compact;
+        d.records = scratch;
         d.record_stride = rc_bytes;
         d.variant_idx = nullptr;
         d.record_off = nullptr;
@@ -406,7 +413,7 @@ static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t re
             LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_PICK:
-            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "pick kernel needs K >= 4, 61 <= N <= 4096 and out_stride == 4K+1");
+            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "pick kernel needs K >= 1, 61 <= N <= 4096 and out_stride == 4K+1");
             LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_WIDE:
@@ -502,7 +509,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_PICK:
-            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_PICK needs K >= 4 and 61 <= N <= 4096");
+            if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_PICK needs K >= 1 and 61 <= N <= 4096");
             LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
             LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;

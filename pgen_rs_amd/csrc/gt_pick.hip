@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
         // a second five-genotype gather (that path runs in every store step on rows of ~1 KB; in-process A/B on the chr22 shape:
         // 5 % kept 0.514 -> 0.545 of roofline, 10 % 0.512 -> 0.563, 20 % 0.565 -> 0.577, >= 30 % +1 %)
         uint32_t *const heads = s_heads[wave];
-        if (lane >= 1u && lane < rows_here) {
+        if (S >= 17u && lane >= 1u && lane < rows_here) {
             const uint8_t *hrow = rows0 + lane * p.pitch;
             v4u ht;
             ht.x = gt_text(pick_code<IDENT>(hrow, s_idx, 0, K));
@@ -258,6 +258,26 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (S < 17u) {
+            // K = 1, 2, 3 (`--include-sam 'IID == "NA20900"'`, /root/reference/README.md:16-21): rows of 5 / 9 / 13 bytes, a 16-byte
+            // chunk spans up to four of them, so it is built byte by byte.  The launch is a record READER here (626 bytes in for 5
+            // out at N = 2 504): what counts is that the batch's records arrive as one wide run and its text leaves as whole chunks.
+            for (uint32_t c = lane; c < n_chunks; c += 64u) {
+                const uint32_t o = head + (c << 4);
+                uint32_t i, pos;
+                split_offset(o, p, i, pos);
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (uint32_t t = 0; t < 16u; t++) {
+                    const uint32_t code = pick_code<IDENT>(rows0 + i * p.pitch, s_idx, (int32_t)(pos >> 2), K);  // (rank K under '\n': table slack)
+                    const uint32_t byte = pos == S - 1u ? 0x0Au : gt_text_byte(code, pos & 3u);
+                    w[t >> 2] |= byte << (8u * (t & 3u));
+                    if (++pos == S) { pos = 0u; i++; }   // a whole chunk lies inside the run: i stays < rows_here
+                }
+                v4u t4 = {w[0], w[1], w[2], w[3]};
+                *reinterpret_cast<v4u *>(run + o) = t4;
+            }
+        } else
         for (uint32_t c = lane; c < n_chunks; c += 64u) {
             const uint32_t o = head + (c << 4);
             uint32_t i, pos;
@@ -317,10 +337,11 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
 
 bool gt_pick_applicable(const EmitArgs &a)
 {
-    // kept subset, record of one tile (16 <= R <= 1024), rows of >= 17 bytes (a 16-B chunk then touches at most two
-    // rows), dense output pitch or full-line mode (rows then go out one by one behind their prefixes)
+    // kept subset, record of one tile (16 <= R <= 1024), at least one kept sample (rows of >= 17 bytes: a 16-B chunk touches at
+    // most two rows; K = 1, 2, 3: up to four, built byte by byte), dense output pitch or full-line mode (rows then go out one
+    // by one behind their prefixes)
     // (kept_idx == NULL: all samples kept — the same kernel with the identity in place of the table)
-    return a.sample_count <= kMaxSamples && a.record_size >= 16u && a.kept_count >= 4u &&
+    return a.sample_count <= kMaxSamples && a.record_size >= 16u && a.kept_count >= 1u &&
            (a.line_off != nullptr || a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull);
 }
 

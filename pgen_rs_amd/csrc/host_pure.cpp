@@ -128,10 +128,23 @@ int pgenhip_vw_walk_index(const pgenhip_vw_header *h, const uint8_t *index, uint
 {
     if (!h || (!index && index_len) || ((!record_type || !record_len || !record_off) && h && h->variant_count))
         return fail(PGENHIP_ERR_BAD_ARG, "NULL argument");
-    if (h->variant_records_offset < 12ull || index_len < h->variant_records_offset - 12ull)
-        return fail(PGENHIP_ERR_BAD_INDEX, "index shorter than the header says");
+    // *h may be caller-made (it is a plain struct of the public ABI): nothing derived is trusted.  The table geometry is
+    // recomputed from variant_count, record_type_bits and record_length_bytes and must agree with what the struct says.
+    if ((h->record_type_bits != 4u && h->record_type_bits != 8u) || h->record_length_bytes < 1u || h->record_length_bytes > 4u)
+        return fail(PGENHIP_ERR_BAD_ARG, "record_type_bits must be 4 or 8 and record_length_bytes 1..4");
     constexpr uint64_t kBlock = 1ull << 16;
-    auto le = [&](uint64_t pos, uint32_t n) {  // little-endian value of n bytes at file offset 12 + pos
+    {
+        const uint64_t blocks = ((uint64_t)h->variant_count + kBlock - 1ull) / kBlock;
+        uint64_t tables = 8ull * blocks;
+        for (uint64_t b = 0; b < blocks; b++) {
+            const uint64_t cnt = std::min<uint64_t>(kBlock, (uint64_t)h->variant_count - b * kBlock);
+            tables += (cnt * h->record_type_bits + 7ull) / 8ull + cnt * h->record_length_bytes;
+        }
+        if (h->block_count != blocks || h->variant_records_offset != 12ull + tables)
+            return fail(PGENHIP_ERR_BAD_ARG, "block_count / variant_records_offset do not follow from variant_count and the record widths");
+        if (index_len < tables) return fail(PGENHIP_ERR_BAD_INDEX, "index shorter than the header says");
+    }
+    auto le = [&](uint64_t pos, uint32_t n) {  // little-endian value of n <= 8 bytes at file offset 12 + pos
         uint64_t v = 0;
         for (uint32_t k = 0; k < n; k++) v |= (uint64_t)index[pos + k] << (8u * k);
         return v;
@@ -158,6 +171,7 @@ int pgenhip_vw_walk_index(const pgenhip_vw_header *h, const uint8_t *index, uint
             record_type[first + i] = t;
             record_len[first + i] = len;
             record_off[first + i] = off;
+            if (off + len < off) return fail(PGENHIP_ERR_BAD_INDEX, "record offsets overflow 64 bits");  // a block offset near 2^64
             off += len;
         }
         pos += types_bytes + cnt * h->record_length_bytes;

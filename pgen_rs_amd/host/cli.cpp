@@ -4,7 +4,7 @@
 //   pgen-hip query  <PFILE_PREFIX> -f|--fstring <EXPR> [-i|--include <EXPR>] [-s|--samples]
 //   pgen-hip filter <PFILE_PREFIX> [--include-var <EXPR>] [--include-sam <EXPR>] [-o|--out <FILE>]
 //
-// Additions (opt-in, not in the reference): --gpus <N>, --block-mib <M>, --stats, --dry-run
+// Additions (opt-in, not in the reference): --gpus <N>, --block-mib <M>, --filter-threads <T>, --stats, --dry-run
 // (filter: write the VCF header only and report the body geometry; needs no GPU).
 // Exit codes: 0 ok; 2 usage error (clap's code); 101 where the reference would panic.
 #include <cstdio>
@@ -30,7 +30,7 @@ const char *kUsage =
     "  help    Print this message\n\n"
     "query  <PFILE_PREFIX> -f, --fstring <QUERY_FSTRING> [-i, --include <QUERY>] [-s, --samples]\n"
     "filter <PFILE_PREFIX> [--include-var <VAR_QUERY>] [--include-sam <SAM_QUERY>] [-o, --out <OUT_FILE>]\n"
-    "       [--gpus <N>] [--shards <S>] [--block-mib <M>] [--write-threads <T>] [--read-threads <T>] [--stats] [--dry-run]\n";
+    "       [--gpus <N>] [--shards <S>] [--block-mib <M>] [--write-threads <T>] [--read-threads <T>] [--filter-threads <T>] [--stats] [--dry-run]\n";
 
 [[noreturn]] void usage_error(const std::string &msg)
 {
@@ -157,11 +157,12 @@ int main(int argc, char **argv)
             return 0;
         }
         if (cmd == "filter") {  // src/main.rs:114-124
-            Args a = parse(argc, argv, 2, {{"include-var", 0}, {"include-sam", 0}, {"out", 'o'}, {"gpus", 0}, {"shards", 0}, {"block-mib", 0}, {"write-threads", 0}, {"read-threads", 0}},
+            Args a = parse(argc, argv, 2, {{"include-var", 0}, {"include-sam", 0}, {"out", 'o'}, {"gpus", 0}, {"shards", 0}, {"block-mib", 0}, {"write-threads", 0}, {"read-threads", 0}, {"filter-threads", 0}},
                            {{"stats", 0}, {"dry-run", 0}});
             if (a.positional.size() != 1) usage_error("the following required arguments were not provided: <PFILE_PREFIX>");
             const Pfile pfile = Pfile::from_prefix(a.positional[0]);
             const std::string out_file = a.get("out").value_or(pfile.pfile_prefix + ".pgen-rs.vcf");  // :121-122
+            const int filter_threads = a.get("filter-threads") ? std::max(1, std::atoi(a.get("filter-threads")->c_str())) : 0;
             if (a.has("dry-run")) {
                 // header + geometry only: the plumbing of BASELINE config 1 without touching a GPU
                 const std::string psam = read_file(pfile.psam_path());
@@ -169,8 +170,8 @@ int main(int argc, char **argv)
                 const StringRecord sam_header = psam_reader.headers();
                 const std::string pvar = read_file(pfile.pvar_path());
                 TsvReader pvar_reader(pvar, Pfile::find_metadata_file_header_start(pvar));
-                const auto vars = Pfile::filter_metadata(pvar_reader, a.get("include-var"));
-                const auto sams = Pfile::filter_metadata(psam_reader, a.get("include-sam"));
+                const auto vars = Pfile::filter_metadata(pvar_reader, a.get("include-var"), filter_threads);
+                const auto sams = Pfile::filter_metadata(psam_reader, a.get("include-sam"), filter_threads);
                 const std::string header = pfile.vcf_header(sams, sam_header);
                 FILE *f = std::fopen(out_file.c_str(), "wb");
                 if (!f) throw PfileError("create " + out_file + ": " + std::strerror(errno));
@@ -187,6 +188,7 @@ int main(int argc, char **argv)
                 return 0;
             }
             OutputOptions opt;
+            opt.filter_threads = filter_threads;
             if (auto g = a.get("gpus")) opt.n_gpus = std::max(1, std::atoi(g->c_str()));
             if (auto sh = a.get("shards")) opt.n_shards = std::max(1, std::atoi(sh->c_str()));
             if (auto w = a.get("write-threads")) opt.write_threads = std::max(1, std::atoi(w->c_str()));

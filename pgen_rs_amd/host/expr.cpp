@@ -76,8 +76,12 @@ std::vector<Token> tokenize(const std::string &src)
                 tk.t = Tok::INT;
                 errno = 0;
                 tk.i = std::strtoll(num.c_str(), nullptr, 10);
-                // evalexpr parses integer literals into i64 and reports what does not fit; never saturate silently
-                if (errno == ERANGE) throw ExprError("expression \"" + src + "\": integer literal " + num + " does not fit 64 bits");
+                // evalexpr 11.3.0 (Cargo.lock:121-124; source not in the mount, PARITY UNPINNED) tokenises a literal as i64 first and,
+                // when that parse fails, as f64: a digit string that does not fit 64 bits is a Float, never a saturated Int
+                if (errno == ERANGE) {
+                    tk.t = Tok::FLOAT;
+                    tk.f = std::strtod(num.c_str(), nullptr);
+                }
             }
             p = q;
         } else if ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '_') {

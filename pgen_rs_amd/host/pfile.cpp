@@ -127,13 +127,21 @@ Pfile Pfile::from_prefix(const std::string &pfile_prefix)
     uint8_t hdr[12];
     ssize_t got = pread(fd, hdr, sizeof hdr, 0);
     if (got != (ssize_t)sizeof hdr) throw PfileError("read " + path + ": failed to fill whole buffer");  // :45 read_exact
-    if (hdr[0] == 0x6C && hdr[1] == 0x1B && hdr[2] != 0x02) {
-        // not the fixed-width mode the reference's tool accepts (:53): the variable-width header walk of src/pgen.rs:21-258
+    if (hdr[0] == 0x6C && hdr[1] == 0x1B && hdr[2] == 0x10) {
+        // the standard variable-width mode: the header walk of src/pgen.rs:21-258.  (Every other mode byte — 0x01 .bed, 0x03 / 0x04
+        // fixed-width dosage, 0x20 / 0x21 — keeps the reference's refusal below, :53: their bytes 3.. are not this header.)
         pgenhip_vw_header vh;
         int vrc = pgenhip_vw_parse_header(hdr, &vh);
         if (vrc == PGENHIP_ERR_BAD_FLAGS)
             throw PfileError(path + ": storage mode 0x" + hex2(hdr[2]) + ": unsupported header format byte (" + pgenhip_last_error_detail() + ")");  // src/pgen.rs:58, :64
         check(vrc, "pgenhip_vw_parse_header");
+        // the header's counts are 32 untrusted bits: nothing is allocated from them before the file has shown that it holds the tables
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) throw PfileError("stat " + path + ": " + std::strerror(errno));
+        const uint64_t file_size = (uint64_t)sb.st_size;
+        if (vh.variant_records_offset > file_size)
+            throw PfileError(path + ": failed to fill whole buffer (the header promises " + std::to_string(vh.variant_records_offset) +
+                             " bytes of offset and type / length tables, the file has " + std::to_string(file_size) + ")");  // src/pgen.rs:147, :219 read_exact
         std::vector<uint8_t> index((size_t)(vh.variant_records_offset - 12ull));
         pread_exact(fd, index.data(), index.size(), 12, path);
         auto types = std::make_shared<std::vector<uint8_t>>(vh.variant_count);
@@ -142,6 +150,10 @@ Pfile Pfile::from_prefix(const std::string &pfile_prefix)
         vrc = pgenhip_vw_walk_index(&vh, index.data(), index.size(), types->data(), lens->data(), offs->data());
         if (vrc == PGENHIP_ERR_BAD_INDEX) throw PfileError(path + ": " + pgenhip_last_error_detail());  // src/pgen.rs:160-165 panic
         check(vrc, "pgenhip_vw_walk_index");
+        // records ascend and do not overlap (the walk checked that), so the last one bounds them all
+        if (vh.variant_count && offs->back() + (uint64_t)lens->back() > file_size)
+            throw PfileError(path + ": variant records run past the end of the file (" + std::to_string(offs->back() + (uint64_t)lens->back()) + " > " +
+                             std::to_string(file_size) + ")");
         pf.storage_mode = hdr[2];
         pf.num_variants = vh.variant_count;
         pf.num_samples = vh.sample_count;
@@ -235,13 +247,13 @@ Pfile::IdxRecords filter_records(TsvReader &reader, const std::optional<std::str
 // and the kept records are concatenated in file order with their indices shifted by the number of
 // records before the piece.  Any error re-runs the serial walk so that the message (record and line
 // numbers) is the one the serial reader gives.
-Pfile::IdxRecords Pfile::filter_metadata(TsvReader &reader, const std::optional<std::string> &query)
+Pfile::IdxRecords Pfile::filter_metadata(TsvReader &reader, const std::optional<std::string> &query, int filter_threads)
 {
     const std::string &data = reader.data();
     const size_t begin = reader.position(), end = reader.end_position();
     const size_t kMinBytesPerThread = 1u << 20;
     size_t n_threads = std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), 16u, (end - begin) / kMinBytesPerThread});
-    if (const char *e = getenv("PGENHIP_FILTER_THREADS")) n_threads = (size_t)std::max(1, atoi(e));
+    if (filter_threads > 0) n_threads = (size_t)filter_threads;  // `--filter-threads` (1 = the serial walk of the reference)
     if (n_threads < 2 || begin >= end || memchr(data.data() + begin, '"', end - begin) != nullptr)
         return filter_records(reader, query, 0);
 
@@ -366,8 +378,8 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     const StringRecord sam_header = psam_reader.headers();  // :112
     const std::string pvar = read_file(pvar_path());
     TsvReader pvar_reader(pvar, find_metadata_file_header_start(pvar));
-    const IdxRecords var_idx_rcds = filter_metadata(pvar_reader, var_query);  // :127
-    const IdxRecords sam_idx_rcs = filter_metadata(psam_reader, sam_query);   // :128
+    const IdxRecords var_idx_rcds = filter_metadata(pvar_reader, var_query, opt.filter_threads);  // :127
+    const IdxRecords sam_idx_rcs = filter_metadata(psam_reader, sam_query, opt.filter_threads);   // :128
     const std::string header = vcf_header(sam_idx_rcs, sam_header);
     st.seconds_filter = now_s() - t0;
 

@@ -29,6 +29,7 @@ struct OutputOptions {
                                                // keeping 20 samples: pinning the staging buffers costs more than bigger launches give (profiles/r02_e2e.md)
     int write_threads = 1;                  // parallel pwrite()s per block and device
     int read_threads = 4;                   // parallel pread()s of one run of consecutive records (runs of >= 64 MiB)
+    int filter_threads = 0;                 // pieces the metadata walk is cut into (0 = by file size and host cores, 1 = serial like the reference)
     bool verbose = false;
 };
 
@@ -57,8 +58,9 @@ class Pfile {
     std::string psam_path() const { return pfile_prefix + ".psam"; }
     std::string pvar_path() const { return pfile_prefix + ".pvar"; }
 
-    // :38-76 — opens PREFIX.pgen and checks magic / storage mode 0x02 / flag byte 0x40; any other storage mode goes through
-    // the variable-width header walk (src/pgen.rs:21-258) and is accepted when its tables are sound
+    // :38-76 — opens PREFIX.pgen and checks magic / storage mode 0x02 / flag byte 0x40; storage mode 0x10 goes through the
+    // variable-width header walk (src/pgen.rs:21-258) and is accepted when the file holds its tables and they are sound;
+    // every other mode is refused like the reference does (:53)
     static Pfile from_prefix(const std::string &pfile_prefix);
 
     // :196-200
@@ -72,7 +74,8 @@ class Pfile {
 
     using IdxRecords = std::vector<std::pair<size_t, StringRecord>>;
     // :312-335 — rows (file order) whose predicate is true; all rows without a query
-    static IdxRecords filter_metadata(TsvReader &reader, const std::optional<std::string> &query);
+    // (filter_threads: 0 = as many pieces as the file size and the host's cores suggest, 1 = the reference's serial walk)
+    static IdxRecords filter_metadata(TsvReader &reader, const std::optional<std::string> &query, int filter_threads = 0);
 
     // :78-102 — prints f_string evaluated on each kept row to `out` (stdout in the CLI)
     static void query_metadata(TsvReader &reader, const std::optional<std::string> &query, const std::string &f_string,

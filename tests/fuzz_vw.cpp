@@ -30,7 +30,7 @@ int main(int argc, char **argv)
     if (seed.size() < 12) return 2;
     const long iters = std::atol(argv[2]);
     rng_state = std::strtoull(argv[3], nullptr, 10);
-    long ok = 0, bad_header = 0, bad_index = 0, compressed = 0, skipped = 0;
+    long ok = 0, bad_header = 0, bad_index = 0, compressed = 0, skipped = 0, struct_refused = 0;
     for (long it = 0; it < iters; it++) {
         std::vector<uint8_t> d = seed;
         const int n_mut = 1 + (int)(rnd() % 4);
@@ -64,6 +64,31 @@ int main(int argc, char **argv)
         std::vector<uint8_t> types(h.variant_count);
         std::vector<uint32_t> lens(h.variant_count);
         std::vector<uint64_t> offs(h.variant_count);
+        // the struct is part of the public ABI and a caller may hand in one it made itself: perturb the DERIVED fields of a copy
+        // (the arrays stay variant_count long).  The walk must refuse what does not follow from variant_count and the widths
+        // — a record_length_bytes > 8 would shift by >= 64, a wrong block_count would walk past the index — or walk clean.
+        if (it % 3 == 0) {
+            pgenhip_vw_header g = h;
+            const uint64_t r = rnd();
+            switch (r & 7) {
+                case 0: g.record_length_bytes = (uint8_t)(r >> 8); break;
+                case 1: g.record_type_bits = (uint8_t)(r >> 8); break;
+                case 2: g.block_count = (r >> 8) % 70000u; break;
+                case 3: g.block_count = r; break;
+                case 4: g.variant_records_offset = (r >> 8) % (2 * h.variant_records_offset + 64); break;
+                case 5: g.variant_records_offset = r; break;
+                case 6: g.main_header_body_offset = r; break;  // not used by the walk: must not matter
+                default: g.record_length_bytes = 0; break;
+            }
+            const int grc = pgenhip_vw_walk_index(&g, index.data(), index.size(), types.data(), lens.data(), offs.data());
+            const bool same = g.record_length_bytes == h.record_length_bytes && g.record_type_bits == h.record_type_bits && g.block_count == h.block_count &&
+                              g.variant_records_offset == h.variant_records_offset;
+            if (!same && h.variant_count && grc == PGENHIP_OK) {
+                std::fprintf(stderr, "iteration %ld: an inconsistent header struct was walked\n", it);
+                return 1;
+            }
+            if (grc == PGENHIP_ERR_BAD_ARG) struct_refused++;
+        }
         rc = pgenhip_vw_walk_index(&h, index.data(), index.size(), types.data(), lens.data(), offs.data());
         if (rc != PGENHIP_OK) {
             bad_index++;
@@ -85,7 +110,7 @@ int main(int argc, char **argv)
         else if (rc == PGENHIP_OK) ok++;
         else return 1;
     }
-    std::printf("fuzz_vw: %ld iterations: %ld walked clean, %ld compressed records, %ld bad header, %ld bad index, %ld skipped\n", iters, ok, compressed, bad_header,
-                bad_index, skipped);
+    std::printf("fuzz_vw: %ld iterations: %ld walked clean, %ld compressed records, %ld bad header, %ld bad index, %ld skipped, %ld perturbed structs refused\n", iters, ok, compressed, bad_header,
+                bad_index, skipped, struct_refused);
     return 0;
 }

@@ -69,7 +69,8 @@ def test_shard_range_is_the_one_partitioner():
 
 def test_no_getenv_on_the_launch_path():
     # launch-shape knobs live in the ctx (pgenhip_tune); the library must not be steered by the process environment
-    for p in (REPO / "pgen_rs_amd" / "csrc").glob("*"):
+    # (nor the host above it: `--filter-threads` is a flag)
+    for p in list((REPO / "pgen_rs_amd" / "csrc").glob("*")) + list((REPO / "pgen_rs_amd" / "host").glob("*")):
         assert "getenv" not in p.read_text(), p
 
 

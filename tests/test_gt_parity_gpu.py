@@ -30,7 +30,7 @@ def kernels_for(subset: bool, dense: bool, n: int = 0, k: int = 0):
         ks.append(_capi.KERNEL_WIDE)
     if subset and n >= 61:  # the scan kernel needs records of >= 16 bytes
         ks.append(_capi.KERNEL_SCAN)
-    if dense and 61 <= n <= 4096 and (k >= 4 if subset else True):
+    if dense and 61 <= n <= 4096 and (k >= 1 if subset else True):
         ks.append(_capi.KERNEL_PICK)  # short records: kept subset through the table, or all samples (identity)
     return ks
 
@@ -289,12 +289,17 @@ def test_sparse_subsets_segment_triples(n):
 
 @pytest.mark.parametrize("n", [61, 64, 100, 257, 1000, 2504, 4093, 4096])
 def test_pick_kernel_short_records(n):
-    """Short-record subset kernel (N <= 4096): K from 4 to N-1 (rows of 17 bytes up), batches that
+    """Short-record subset kernel (N <= 4096): K from 1 to N-1 (K = 1, 2, 3: rows of 5 / 9 / 13 bytes, a 16-byte chunk spans up
+    to four rows — the README's `IID == "NA20900"` example; rows of 17 bytes up: at most two), batches that
     end mid-way (V not a multiple of the batch), unaligned output pointers (the run's head and tail
     edges), a gapped variant list and a padded record stride; sentinel bytes stay untouched."""
     rng = np.random.default_rng(1200 + n)
     r = oracle.variant_record_size(n)
     masks = {
+        "k1": np.array([n * 2 // 3]),
+        "k1_last": np.array([n - 1]),
+        "k2": np.sort(rng.choice(n, size=2, replace=False)),
+        "k3_ends": np.array([0, n // 2, n - 1]),
         "k4": np.sort(rng.choice(n, size=4, replace=False)),
         "k5_ends": np.unique(np.concatenate([[0, n - 1], rng.choice(n, size=3, replace=False)])),
         "1pct": np.sort(rng.choice(n, size=max(4, n // 100), replace=False)),
@@ -401,6 +406,53 @@ def test_launches_of_one_ctx_on_different_streams_overlap():
         out = eng.decode_emit(recs[0], v)
         eng.wait()
         assert out.cpu().numpy().tobytes() == oracle.decode_emit(recs[0][: v * r].cpu().numpy(), v, n).tobytes()
+
+
+@pytest.mark.parametrize("lines", [False, True])
+def test_two_pass_launches_of_one_ctx_on_different_streams_overlap(lines):
+    """The same promise on the TWO-PASS path (sparse keeps on long records, BASELINE configs[4]'s band): pass 1 parks a
+    chunk's compact records in ctx scratch, pass 2 reads them back.  Every launch in flight has its own slice of that
+    scratch (round 2 had ONE per ctx: overlapping launches on two streams read each other's records — ADVICE r2 medium).
+    9 launches of ONE ctx round-robin on three streams, small chunks (several chunk rounds per launch) and few blocks per
+    CU so that the launches really interleave; every output against the oracle."""
+    n, v = 40_000, 1501
+    kept = np.sort(np.random.default_rng(77).choice(n, size=n // 100 if not lines else 1100, replace=False)).astype(np.uint32)
+    r = oracle.variant_record_size(n)
+    k = len(kept)
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        eng.tune(_capi.KNOB_SCAN_CHUNK_ROWS, 200)
+        eng.tune(_capi.KNOB_SCAN_BLOCKS_PER_CU, 1)
+        eng.tune(_capi.KNOB_WIDE_BLOCKS_PER_CU, 1)
+        streams = [torch.cuda.Stream(device=DEV) for _ in range(3)]
+        recs, outs = [], []
+        if lines:
+            plen = np.random.default_rng(5).integers(3, 60, size=v).astype(np.int64)
+            poff = np.concatenate([[0], np.cumsum(plen)]).astype(np.int64)
+            loff = np.concatenate([[0], np.cumsum(plen + 4 * k + 1)]).astype(np.int64)
+            blob = np.random.default_rng(6).integers(65, 91, size=int(poff[-1]), dtype=np.uint8)
+            d_blob, d_poff, d_loff = (torch.from_numpy(x).to(DEV) for x in (blob, poff, loff))
+            out_bytes = int(loff[-1])
+        else:
+            out_bytes = v * (4 * k + 1)
+        for i in range(9):
+            recs.append(eng.synth_records(v, first_variant=777 * i))
+            outs.append(torch.full((out_bytes,), SENTINEL, dtype=torch.uint8, device=DEV))
+        torch.cuda.synchronize()
+        for i in range(9):
+            eng.use_stream(streams[i % 3])
+            if lines:
+                eng.emit_lines(recs[i], v, d_blob, d_poff, d_loff, int(plen.max()), outs[i])
+            else:
+                eng.decode_emit(recs[i], v, out=outs[i])
+        torch.cuda.synchronize()
+        eng.use_torch_stream()
+        for i in range(9):
+            host = recs[i][: v * r].cpu().numpy()
+            if lines:
+                want = oracle.emit_lines(host, v, n, blob, poff.astype(np.uint64), loff.astype(np.uint64), kept_idx=kept).tobytes()
+            else:
+                want = oracle.decode_emit(host, v, n, kept_idx=kept).tobytes()
+            assert outs[i].cpu().numpy().tobytes() == want, f"launch {i}"
 
 
 @pytest.mark.parametrize("n,kept_frac", [(2504, None), (2504, 0.3), (40000, 0.01), (700, None)])
@@ -667,7 +719,8 @@ def test_emit_lines_tiny_keep_lists(n, k):
     assert want.size == sum(len(q) for q in prefixes) + v * (4 * k + 1)
     with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
         assert eng.kept_count == k and eng.gt_row_bytes == 4 * k + 1
-        for kernel in (_capi.KERNEL_AUTO, _capi.KERNEL_ROWS, _capi.KERNEL_SCAN):
+        forced = (_capi.KERNEL_AUTO, _capi.KERNEL_ROWS, _capi.KERNEL_SCAN) + ((_capi.KERNEL_PICK,) if k >= 1 and n <= 4096 else ())
+        for kernel in forced:
             out = torch.full((3 + int(loff[-1]) + 48,), SENTINEL, dtype=torch.uint8, device=DEV)
             eng.emit_lines(torch.from_numpy(recs).to(DEV), v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV),
                            torch.from_numpy(loff).to(DEV), 50, out[3:], kernel=kernel)
@@ -676,7 +729,7 @@ def test_emit_lines_tiny_keep_lists(n, k):
             assert (got[:3] == SENTINEL).all() and (got[3 + want.size :] == SENTINEL).all(), f"kernel {kernel} wrote outside the lines"
             assert bytes(got[3 : 3 + want.size]) == want.tobytes(), f"kernel {kernel}"
         # GT segments only (pgenhip_decode_emit): rows of 4K+1 bytes, K = 0 -> one '\n' per row
-        for kernel in (_capi.KERNEL_AUTO, _capi.KERNEL_ROWS, _capi.KERNEL_SCAN):
+        for kernel in forced:
             out = torch.full((v * (4 * k + 1) + 32,), SENTINEL, dtype=torch.uint8, device=DEV)
             eng.decode_emit(torch.from_numpy(recs).to(DEV), v, out=out, kernel=kernel)
             eng.wait()

@@ -105,6 +105,10 @@ def test_ragged_record_is_an_error(tmp_path):
     ('POS < "15"', b"r1\n"),                                         # strings order lexicographically
     ('1 + 2 * 3 == 7 && POS != "20"', b"r1\n"),
     ('true', b"r1\nr2\n"),
+    # a digit string that does not fit i64 is a Float literal in evalexpr (i64 parse first, then f64), not an error and not a
+    # saturated Int: Float == Int is false, Float > Int compares numerically (evalexpr's source is absent: unpinned)
+    ('99999999999999999999 == 0', b""),
+    ('99999999999999999999 > 9223372036854775807 && POS == "10"', b"r1\n"),
 ])
 def test_expression_subset(tmp_path, expr, want):
     pre = write_meta(tmp_path, b"#CHROM\tPOS\tID\n1\t10\tr1\n2\t20\tr2\n", PSAM)
@@ -126,7 +130,6 @@ def test_expression_subset(tmp_path, expr, want):
     ["-i", "(0 - 9223372036854775807 - 1) / (0 - 1) == 0", "-f", "ID"],
     ["-i", "(0 - 9223372036854775807 - 1) % (0 - 1) == 0", "-f", "ID"],
     ["-i", "-(0 - 9223372036854775807 - 1) == 0", "-f", "ID"],
-    ["-i", "99999999999999999999 == 0", "-f", "ID"],
     ["-i", "1 / 0 == 0", "-f", "ID"],
 ])
 def test_expression_errors_exit_101(tmp_path, args):
@@ -138,7 +141,7 @@ def test_expression_errors_exit_101(tmp_path, args):
 def test_header_asserts_and_usage(tmp_path):
     pre = write_meta(tmp_path, b"#CHROM\tPOS\tID\n1\t10\tr1\n", PSAM)
     raw = bytearray((tmp_path / "t.pgen").read_bytes())
-    for pos, val in ((0, 0x6D), (2, 0x10), (11, 0x00)):  # src/pfile.rs:47, :53, :69
+    for pos, val in ((0, 0x6D), (2, 0x10), (2, 0x01), (2, 0x03), (2, 0x20), (11, 0x00)):  # src/pfile.rs:47, :53, :69
         bad = bytearray(raw)
         bad[pos] = val
         (tmp_path / "t.pgen").write_bytes(bytes(bad))
@@ -153,6 +156,34 @@ def test_header_asserts_and_usage(tmp_path):
     assert p.returncode == 101 and b"IID not among the headers" in p.stderr
 
 
+def test_untrusted_header_counts_allocate_nothing(tmp_path):
+    """a 12-byte file claiming mode 0x10 and 2^32-1 variants used to make from_prefix allocate the offset and
+    type / length tables (tens of GB, zero-filled) before looking at the file size.  Now: fstat first — exit 101 at once, and
+    only mode 0x10 takes the variable-width walk (0x01 .bed, 0x03 / 0x04 dosage, 0x20 / 0x21 keep the reference's refusal, :53)."""
+    import resource
+    import time
+
+    pre = write_meta(tmp_path, b"#CHROM\tPOS\tID\n1\t10\tr1\n", PSAM)
+    (tmp_path / "t.pgen").write_bytes(bytes([0x6C, 0x1B, 0x10]) + (0xFFFFFFFF).to_bytes(4, "little") + (2504).to_bytes(4, "little") + b"\x40")
+    t0 = time.time()
+    p = subprocess.run([str(CLI), "query", str(pre), "-f", "ID"], capture_output=True,
+                       preexec_fn=lambda: resource.setrlimit(resource.RLIMIT_AS, (2 << 30, 2 << 30)))  # a 2-GiB address space is plenty
+    assert p.returncode == 101 and b"failed to fill whole buffer" in p.stderr, p.stderr
+    assert time.time() - t0 < 5
+    # tables present but the records are not: the last record must end inside the file
+    import numpy as np
+    from helpers import GOLDEN as G
+    any_vw = sorted((G / "vw").glob("*.pgen"))[0]
+    data = any_vw.read_bytes()
+    (tmp_path / "t.pgen").write_bytes(data[:-1])
+    p = run("query", str(pre), "-f", "ID")
+    assert p.returncode == 101 and b"past the end of the file" in p.stderr, p.stderr
+    for mode in (0x01, 0x03, 0x04, 0x20, 0x21):
+        (tmp_path / "t.pgen").write_bytes(bytes([0x6C, 0x1B, mode]) + (1).to_bytes(4, "little") + (3).to_bytes(4, "little") + b"\x40\x00")
+        p = run("query", str(pre), "-f", "ID")
+        assert p.returncode == 101 and b"storage_mode == 0x02" in p.stderr, (mode, p.stderr)
+
+
 def test_default_output_name_and_no_gpu_is_loud(basic1, tmp_path):
     import torch
 
@@ -164,7 +195,7 @@ def test_default_output_name_and_no_gpu_is_loud(basic1, tmp_path):
 
 def test_parallel_metadata_filter_matches_serial(tmp_path):
     """N2: the pvar walk split between threads keeps the same records with the same indices as
-    the serial walk (PGENHIP_FILTER_THREADS=1), reports the same error for a ragged row in a late
+    the serial walk (--filter-threads 1), reports the same error for a ragged row in a late
     piece, and stays serial when the file has a quote (a quoted field may hold a line break)."""
     import os
 
@@ -176,13 +207,9 @@ def test_parallel_metadata_filter_matches_serial(tmp_path):
     pre = write_meta(tmp_path, body, PSAM, n=3, v=150_000)
 
     def dry(threads, expr='ALT == "G" || POS == "16050007"'):
-        env = dict(os.environ)
-        if threads is None:
-            env.pop("PGENHIP_FILTER_THREADS", None)
-        else:
-            env["PGENHIP_FILTER_THREADS"] = str(threads)
-        return subprocess.run([str(CLI), "filter", str(pre), "--include-var", expr, "--dry-run", "-o", str(tmp_path / "o.vcf")],
-                              capture_output=True, env=env)
+        extra = [] if threads is None else ["--filter-threads", str(threads)]
+        return subprocess.run([str(CLI), "filter", str(pre), "--include-var", expr, "--dry-run", "-o", str(tmp_path / "o.vcf"), *extra],
+                              capture_output=True)
 
     serial = dry(1)
     assert serial.returncode == 0, serial.stderr

@@ -65,8 +65,8 @@ def test_parallel_metadata_filter_under_asan_and_tsan(asan_cli, tmp_path):
     args = ["filter", str(tmp_path / "basic1"), "--include-var", 'ALT=="G"', "--dry-run", "-o", str(tmp_path / "h.vcf")]
     outs = []
     for threads in ("1", "4"):
-        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", PGENHIP_FILTER_THREADS=threads)
-        p = subprocess.run([str(asan_cli), *args], capture_output=True, env=env)
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+        p = subprocess.run([str(asan_cli), *args, "--filter-threads", threads], capture_output=True, env=env)
         assert p.returncode == 0, p.stderr.decode()[-2000:]
         outs.append(p.stdout)
     assert outs[0] == outs[1] and b'"variants_kept": 4130' in outs[0]
@@ -77,8 +77,8 @@ def test_parallel_metadata_filter_under_asan_and_tsan(asan_cli, tmp_path):
            "-L", str(REPO / "pgen_rs_amd"), "-lpgen_hip", f"-Wl,-rpath,{REPO / 'pgen_rs_amd'}"]
     p = subprocess.run(cmd, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
-    env = dict(os.environ, PGENHIP_FILTER_THREADS="4", TSAN_OPTIONS="halt_on_error=1")
-    p = subprocess.run([str(tsan), *args], capture_output=True, env=env)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    p = subprocess.run([str(tsan), *args, "--filter-threads", "4"], capture_output=True, env=env)
     assert p.returncode == 0 and p.stdout == outs[0], p.stderr.decode()[-3000:]
     assert b"ThreadSanitizer" not in p.stderr
 

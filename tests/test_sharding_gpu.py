@@ -66,6 +66,45 @@ def test_bench_multi_rank_path_rehearsal():
     assert abs(line["value"] - 200_001 * 2504 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-6
 
 
+def test_bench_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` the way the driver starts N = 1 — no torchrun, no WORLD_SIZE: the parent (which never
+    touches a GPU) runs the torch.distributed.run job as a child, relays rank 0's line and returns its exit code.  On
+    the c4 preset with a small variant count, so the N > 1 `secondary.c5` leg (configs[4] on the resident records) runs too."""
+    import os
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo",
+                        "--all-ranks-on-device0", "--config", "c4", "--variants", "4001"], capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["variants_total"] == 4001 and line["config"]["variants_this_rank"] == 2001
+    assert line["config"]["samples"] == 500_000 and line["self_check"]["ok"]
+    c5 = line["secondary"]["c5"]
+    assert 4000 < c5["kept_samples"] < 6000  # the splitmix64 1 % mask
+    assert c5["self_check_ok"] and c5["value"] > 0 and 0 < c5["read_only_frac"] < 1
+    # a failing child is a failing parent (bad flag -> argparse exit 2 in every rank)
+    bad = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--all-ranks-on-device0", "--config", "nope"],
+                         capture_output=True, text=True, timeout=300, cwd=str(REPO), env=env)
+    assert bad.returncode != 0
+
+
+def test_bench_single_gpu_line_carries_the_secondary_shapes():
+    """N = 1 on the c3 preset (small variant count): `secondary` holds configs[4]'s per-GPU shard (north_star's HBM-read target),
+    the chr22 block and the reference's own dataset shape, each self-checked, measured after the headline."""
+    p = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "2", "--warmup", "1", "--variants", "3001", "--no-cpu-baseline", "--no-host-delivered"],
+                       capture_output=True, text=True, timeout=900, cwd=str(REPO))
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    sec = line["secondary"]
+    assert set(sec) == {"c5shard", "chr22", "basic2"}
+    for name, s in sec.items():
+        assert s["self_check_ok"] and s["ms_per_step"] > 0 and 0 < s["frac"] < 1, name
+    assert sec["c5shard"]["variants"] == 125_000 and sec["c5shard"]["samples"] == 500_000 and 4000 < sec["c5shard"]["kept_samples"] < 6000
+    assert sec["c5shard"]["read_only_frac"] > 0.3   # the target is 0.5; this only guards against a broken measurement
+
+
 def test_cli_two_gpus_two_shards(tmp_path):
     """`pgen-hip filter --gpus 2 --shards 2`: per-device worker threads with their own contexts; needs 2 devices."""
     if pgen_rs_amd.device_count() < 2:
