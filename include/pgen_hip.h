@@ -167,6 +167,7 @@ uint64_t pgenhip_gt_row_bytes(const pgenhip_ctx *ctx);
 /* 5u was round 1's stream-span kernel (measured level with WIDE, removed) */
 #define PGENHIP_KERNEL_PICK 6u   /* kept subset on short records (61 <= N <= 4096, K >= 1, dense pitch): output-driven pick through the kept list */
 #define PGENHIP_KERNEL_RUNS 7u   /* dense all-samples on SHORT rows (8 <= N <= ~2000, dense records, no gather): runs of rows as one work item */
+#define PGENHIP_KERNEL_ROWPICK 8u /* sparse kept subset (1 <= K <= 16384) on long records: one wave per row, the row's compact record assembled in LDS, text written in one go; any strides */
 #define PGENHIP_KERNEL_MASK 0xFu
 
 /* src/pfile.rs:165-190 for a block of n_variants kept variants.
@@ -197,7 +198,7 @@ int pgenhip_decode_emit_at(pgenhip_ctx *ctx, const void *d_base, const uint64_t 
  * stream kernel writes each GT segment in place behind its prefix and a small kernel copies
  * the prefixes; a kept subset on records of >= 16 bytes: the scan-family kernels write the GT
  * segments and the same small kernel the prefixes; otherwise the general kernel),
- * PGENHIP_KERNEL_ROWS, PGENHIP_KERNEL_WIDE, PGENHIP_KERNEL_SCAN or PGENHIP_KERNEL_PICK to force one (tests, A/B). */
+ * PGENHIP_KERNEL_ROWS, PGENHIP_KERNEL_WIDE, PGENHIP_KERNEL_SCAN, PGENHIP_KERNEL_PICK, PGENHIP_KERNEL_RUNS or PGENHIP_KERNEL_ROWPICK to force one (tests, A/B). */
 int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
                        const uint32_t *d_variant_idx, uint32_t n_variants,
                        const void *d_prefix_blob, const uint64_t *d_prefix_off,
@@ -216,6 +217,8 @@ typedef enum pgenhip_knob {
     PGENHIP_KNOB_SCAN_XCD_MAP = 8,       /* segment kernels: 1 (default) all blocks of a row group on one XCD, -1 plain block map */
     PGENHIP_KNOB_SCAN_TWO_PASS = 9,      /* sparse keeps on long records: 1 (default) compact pass + all-samples pass, -1 single-pass segment kernel */
     PGENHIP_KNOB_SCAN_CHUNK_ROWS = 10,   /* two-pass path: rows per chunk (default: as many as the 64-MiB compact scratch holds) */
+    PGENHIP_KNOB_ROWPICK_BLOCKS_PER_CU = 11, /* row-owner kernel: cap on resident blocks per CU (default: occupancy API) */
+    PGENHIP_KNOB_SCAN_ROWPICK = 12,      /* sparse keeps on long records, chunks of many rows: 1 (default) the row-owner kernel as the compact pass of the two passes, 2 the row-owner kernel writing text in ONE pass, -1 the segment kernel as the compact pass */
     PGENHIP_KNOB_RUNS_ROWS = 7           /* RUNS kernel: rows per work item (default: as many as one wide load / one span holds) */
 } pgenhip_knob;
 int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value);

@@ -39,6 +39,7 @@ KERNEL_SCAN = 3
 KERNEL_WIDE = 4
 KERNEL_PICK = 6
 KERNEL_RUNS = 7
+KERNEL_ROWPICK = 8
 SYNTH_DIRTY_PAD = 1
 SYNTH_HWE = 2
 CREATE_KEEP_LIST = 1
@@ -53,6 +54,8 @@ KNOB_RUNS_ROWS = 7
 KNOB_SCAN_XCD_MAP = 8
 KNOB_SCAN_TWO_PASS = 9
 KNOB_SCAN_CHUNK_ROWS = 10
+KNOB_ROWPICK_BLOCKS_PER_CU = 11
+KNOB_SCAN_ROWPICK = 12
 
 
 

@@ -21,7 +21,7 @@ REPO_ROOT = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 HIP_LIB = PKG_DIR / "libpgen_hip.so"
 
-HIP_SOURCES = ["capi.hip", "host_pure.cpp", "gt_rows.hip", "gt_flat.hip", "gt_wide.hip", "gt_scan.hip", "gt_pick.hip"]
+HIP_SOURCES = ["capi.hip", "host_pure.cpp", "gt_rows.hip", "gt_flat.hip", "gt_wide.hip", "gt_scan.hip", "gt_pick.hip", "gt_rowpick.hip"]
 HIPCC_FLAGS = [
     "-O3",
     "-std=c++17",

@@ -271,6 +271,16 @@ static bool very_sparse(const pgenhip_ctx *ctx)
     return ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 280ull <= ctx->sample_count;
 }
 
+// Sparse keeps on long records with many rows in the launch, ONE pass through the row-owner kernel (gt_rowpick.hip writing text):
+// opt-in (PGENHIP_KNOB_SCAN_ROWPICK = 2).  Measured on BASELINE configs[4]'s shard it is 3-6 % BEHIND the two passes (3.33-3.67 ms
+// against 3.27-3.40): a launch that reads 86 % and writes 14 % of its bytes everywhere at once runs at the copy ceiling (5.4 TB/s
+// of total traffic), while a pass that only reads followed by a pass that only writes run at 5.8 and 4.7 (profiles/r03_kernel_sweeps.md).
+// The default use of that kernel is as the COMPACT pass of the two passes (dispatch_two_pass).
+static bool rowpick_shape(const pgenhip_ctx *ctx, const EmitArgs &a)
+{
+    return ctx->tune.scan_rowpick == 2 && two_pass_shape(ctx->sample_count, ctx->kept_count) && !very_sparse(ctx) && gt_rowpick_applicable(a, ctx->num_cus);
+}
+
 // AUTO for all samples kept, GT segments at a.out + j * a.out_stride
 static int dispatch_all_samples(pgenhip_ctx *ctx, const EmitArgs &a)
 {
@@ -320,12 +330,14 @@ static int dispatch_all_samples_lines(pgenhip_ctx *ctx, const EmitArgs &a)
     return PGENHIP_OK;
 }
 
-// Two passes for sparse keeps on long records, chunk by chunk of as many rows as the compact scratch holds: (1) the segment kernel
-// compacts each row's kept codes into a K-sample record, (2) the all-samples dispatch above turns those records into text.
+// Two passes for sparse keeps on long records, chunk by chunk of as many rows as the compact scratch holds: (1) the row-owner kernel
+// (chunks of many rows; else the segment kernel) compacts each row's kept codes into a K-sample record, (2) the all-samples
+// dispatch above turns those records into text.
 static bool two_pass(const pgenhip_ctx *ctx, const EmitArgs &a)
 {
     // (full lines: only where the second pass is the stream kernel's LINES mode, K >= 1 024 — below that it would flush row by row)
     return ctx->tune.scan_two_pass != 0 && ctx->d_compact != nullptr && a.kept_idx != nullptr && a.record_size >= 16u &&
+           ctx->max_seg_count <= kCompactMaxSegCodes &&
            (a.line_off != nullptr ? a.kept_count >= 1024u : (a.n_variants <= 1u || a.out_stride == 4ull * a.kept_count + 1ull));
 }
 
@@ -335,6 +347,15 @@ static int dispatch_two_pass(pgenhip_ctx *ctx, const EmitArgs &a, const ScanArgs
     uint8_t *const scratch = ctx->d_compact + (size_t)ctx->launch_slot * ctx->compact_bytes;  // this launch's own slice
     uint64_t chunk_rows = std::max<uint64_t>(1ull, ctx->compact_bytes / rc_bytes);
     if (ctx->tune.scan_chunk_rows > 0) chunk_rows = std::min<uint64_t>(chunk_rows, (uint64_t)ctx->tune.scan_chunk_rows);
+    // the row-owner compact pass deals rows to its resident waves round-robin: whole rounds per chunk
+    bool row_owner = false;
+    if (ctx->tune.scan_rowpick != 0) {
+        EmitArgs probe = a;
+        probe.n_variants = (uint32_t)std::min<uint64_t>(chunk_rows, a.n_variants);
+        row_owner = gt_rowpick_applicable(probe, ctx->num_cus);
+        const uint64_t round = gt_rowpick_resident_waves(probe, ctx->tune, ctx->num_cus, true);
+        if (row_owner && round && chunk_rows > round && ctx->tune.scan_chunk_rows <= 0) chunk_rows -= chunk_rows % round;
+    }
     for (uint64_t row0 = 0; row0 < a.n_variants; row0 += chunk_rows) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(chunk_rows, (uint64_t)a.n_variants - row0);
         EmitArgs c = a;  // pass 1: this chunk's rows -> compact records
@@ -347,7 +368,10 @@ static int dispatch_two_pass(pgenhip_ctx *ctx, const EmitArgs &a, const ScanArgs
         c.prefix_blob = nullptr;
         c.prefix_off = nullptr;
         c.line_off = nullptr;
-        LAUNCH_TRY(launch_gt_scan(c, sc, ctx->tune, ctx->num_cus, ctx->stream, true));
+        if (row_owner && (uint64_t)n * 2ull >= chunk_rows)   // (a short last chunk: the segment kernel cuts it finer)
+            LAUNCH_TRY(launch_gt_rowpick(c, sc, ctx->tune, ctx->num_cus, ctx->stream, true));   // a wave per row: whole compact records, wide stores
+        else
+            LAUNCH_TRY(launch_gt_scan(c, sc, ctx->tune, ctx->num_cus, ctx->stream, true));
         EmitArgs d = a;  // pass 2: a block of n mode-0x02 records of K samples, all of them kept
         d.records = scratch;
         d.record_stride = rc_bytes;
@@ -394,6 +418,10 @@ static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t re
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;  // `--include-sam` that keeps everybody: same bytes, the all-samples kernels
             if (a.kept_idx == nullptr) return dispatch_all_samples(ctx, a);
+            if (rowpick_shape(ctx, a)) {
+                LAUNCH_TRY(launch_gt_rowpick(a, sc, t, ctx->num_cus, ctx->stream));
+                return PGENHIP_OK;
+            }
             if (two_pass(ctx, a) && !very_sparse(ctx))
                 return dispatch_two_pass(ctx, a, sc);
             if (gt_pick_applicable(a))
@@ -411,6 +439,11 @@ static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t re
             if (!ctx->subset) return fail(PGENHIP_ERR_BAD_ARG, "segment kernels need a kept-sample list");
             if (ctx->record_size < 16u) return fail(PGENHIP_ERR_BAD_ARG, "segment kernels need N >= 61 (records of >= 16 bytes)");
             LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
+        case PGENHIP_KERNEL_ROWPICK:
+            if (!ctx->subset || ctx->record_size < 16u || ctx->kept_count < 1u || ctx->kept_count > kRowPickMaxKept)
+                return fail(PGENHIP_ERR_BAD_ARG, "row-owner kernel needs a kept-sample list of 1 .. 16384 samples and N >= 61");
+            LAUNCH_TRY(launch_gt_rowpick(a, sc, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_PICK:
             if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "pick kernel needs K >= 1, 61 <= N <= 4096 and out_stride == 4K+1");
@@ -473,6 +506,10 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;
             if (a.kept_idx == nullptr) return dispatch_all_samples_lines(ctx, a);
+            if (rowpick_shape(ctx, a)) {
+                LAUNCH_TRY(launch_gt_rowpick(a, sc, t, ctx->num_cus, ctx->stream));   // (writes the prefixes too)
+                return PGENHIP_OK;
+            }
             if (two_pass(ctx, a) && !very_sparse(ctx)) return dispatch_two_pass(ctx, a, sc);
             if (gt_lineruns_applicable(a) && gt_lineruns_rows(a) >= 7u) {
                 // kept subset on SHORT dense records: runs of whole lines through the line-run kernel, picks through its LDS kept table.
@@ -508,13 +545,18 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
             if (!gt_lineruns_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_RUNS (lines) needs dense records, >= 8 kept samples (of <= 4096 with a keep list) and two lines per item");
             LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
+        case PGENHIP_KERNEL_ROWPICK:
+            if (!ctx->subset || ctx->record_size < 16u || ctx->kept_count < 1u || ctx->kept_count > kRowPickMaxKept)
+                return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_ROWPICK needs a kept-sample list of 1 .. 16384 samples and N >= 61");
+            LAUNCH_TRY(launch_gt_rowpick(a, sc, t, ctx->num_cus, ctx->stream));
+            return PGENHIP_OK;
         case PGENHIP_KERNEL_PICK:
             if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_PICK needs K >= 1 and 61 <= N <= 4096");
             LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
             LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         default:
-            return fail(PGENHIP_ERR_BAD_ARG, "pgenhip_emit_lines supports kernel flags AUTO, ROWS, WIDE, SCAN, PICK and RUNS");
+            return fail(PGENHIP_ERR_BAD_ARG, "pgenhip_emit_lines supports kernel flags AUTO, ROWS, WIDE, SCAN, PICK, RUNS and ROWPICK");
     }
 }
 
@@ -535,6 +577,8 @@ int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value)
         case PGENHIP_KNOB_SCAN_XCD_MAP: t.scan_xcd_map = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_SCAN_CHUNK_ROWS: t.scan_chunk_rows = value > 0 ? value : d.scan_chunk_rows; break;
         case PGENHIP_KNOB_SCAN_TWO_PASS: t.scan_two_pass = value < 0 ? 0 : 1; break;
+        case PGENHIP_KNOB_ROWPICK_BLOCKS_PER_CU: t.rowpick_blocks_per_cu = value > 0 ? value : d.rowpick_blocks_per_cu; break;
+        case PGENHIP_KNOB_SCAN_ROWPICK: t.scan_rowpick = value < 0 ? 0 : (value == 2 ? 2 : 1); break;
         case PGENHIP_KNOB_RUNS_ROWS: t.runs_rows = value > 0 ? value : d.runs_rows; break;
         default: return fail(PGENHIP_ERR_BAD_ARG, "unknown knob");
     }

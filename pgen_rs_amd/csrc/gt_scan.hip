@@ -64,13 +64,7 @@ constexpr uint32_t kStageBytes = kSegSamples / 4u;                   // one row'
 // SLOWER at 0.33-5 % kept: this kernel wants few, fat waves; profiles/r02_kernel_sweeps.md.)
 constexpr uint32_t kPickMaxSegCodes = kSegSamples;             // up to a fully kept segment: 32 KiB of LDS for the table
 
-// COMPACT instantiation (first pass of the two-pass path for sparse keeps, launch_gt_scan): instead of text the block writes
-// its part of each row's COMPACT record to a.out + j * a.out_stride — the K kept codes packed four to a byte exactly like a
-// mode-0x02 record of K samples (src/pfile.rs:171-175 applied here; :177-190 by the all-samples kernels in the second pass).
-// Byte b of a compact record belongs to the segment that owns rank 4b: a block writes bytes ceil(k0/4) .. ceil(k1/4)-1 of its
-// rank slice [k0, k1) and fetches the up to three ranks behind k1 that share its last byte straight from the record (their
-// samples live in later segments) — no byte is written twice, nothing needs zeroing.
-template <bool HAS_VIDX, bool COMPACT = false>
+template <bool HAS_VIDX>
 __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups, uint32_t xcd_groups, uint32_t bands)
 {
     __shared__ uint16_t s_idx[kPickMaxSegCodes + 8];
@@ -105,18 +99,9 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
 
     if (seg_cnt == 0u) {
         // nothing of this segment is kept; the last segment still owes every row its '\n' (:190)
-        if (!COMPACT && last_seg)
+        if (last_seg)
             for (uint64_t n = lane; n < rows; n += 64ull) row_text(a, j0 + n * row_step)[4ull * K] = (uint8_t)'\n';
         return;
-    }
-    // COMPACT: bytes of the compact record this block owns, and the ranks behind its slice that share its last byte
-    const uint32_t seg_k1 = seg_k0 + seg_cnt;
-    const uint32_t cb0 = (seg_k0 + 3u) >> 2, cb1 = (seg_k1 + 3u) >> 2;
-    const uint32_t n_foreign = COMPACT ? min((cb1 << 2) - seg_k1, K - seg_k1) : 0u;   // 0 .. 3
-    uint32_t f_smp = 0u;  // lane i < n_foreign: sample of rank seg_k1 + i
-    if (COMPACT) {
-        if (cb0 == cb1) return;  // every rank of the slice sits in a byte an earlier segment owns
-        if (lane < n_foreign) f_smp = a.kept_idx[seg_k1 + lane];
     }
     for (uint32_t r = tid; r < seg_cnt + 8u; r += (uint32_t)kThreads)
         s_idx[r] = r < seg_cnt ? (uint16_t)(a.kept_idx[seg_k0 + r] - seg * kSegSamples) : (uint16_t)0;  // 8 entries of slack for the flush's fifth code
@@ -133,8 +118,8 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     const uint32_t tail_shift = tail_b + 16u <= R ? 0u : min(tail_b - (R - 16u), 16u);
     // (full lines: where the row's GT segment starts — line_off + prefix length — travels with the row's loads, a row ahead,
     // instead of three dependent loads in front of every flush)
-    const bool lines = !COMPACT && a.line_off != nullptr;
-    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg], uint32_t &fbyte, uint64_t &toff) {
+    const bool lines = a.line_off != nullptr;
+    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg], uint64_t &toff) {
         const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
         if (lines) toff = a.line_off[row] + (a.prefix_off[row + 1ull] - a.prefix_off[row]);
         const uint8_t *__restrict__ rec = HAS_VIDX ? gathered_record(a, row) : a.records + row * a.record_stride;
@@ -144,9 +129,8 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
             const uint8_t *src16 = tile0 + t < tail_t ? sub + lane * 16u + t * 1024u : rec + tail_off;
             __builtin_memcpy(&dst[t], src16, 16);
         }
-        if (COMPACT && lane < n_foreign) fbyte = rec[f_smp >> 2];  // the record byte of a rank behind the slice (a later segment's sample)
     };
-    auto emit_row = [&](uint64_t n, const v4u(&w)[kTilesPerSeg], uint32_t fbyte, uint64_t toff) {
+    auto emit_row = [&](uint64_t n, const v4u(&w)[kTilesPerSeg], uint64_t toff) {
         // park the row's segment bytes (segment byte b at stage[b])
 #pragma unroll
         for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
@@ -161,30 +145,6 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (COMPACT) {
-            // lane <-> compact byte b = ranks 4b .. 4b+3 (src/pfile.rs:171-175: rank -> sample -> bits 2*(s%4) of byte s/4)
-            uint8_t *const crow = a.out + (j0 + n * row_step) * a.out_stride;
-            // the foreign ranks' codes, wave-uniform: rank seg_k1 + i sits at bits 2 * ((seg_k1 + i) & 3) of the last owned byte
-            uint32_t f_bits = 0u;
-            const uint32_t f_code = (fbyte >> ((f_smp & 3u) * 2u)) & 3u;
-            for (uint32_t i = 0; i < n_foreign; i++)
-                f_bits |= (uint32_t)__builtin_amdgcn_readlane((int)f_code, (int)i) << (2u * ((seg_k1 + i) & 3u));
-            for (uint32_t b = cb0 + lane; b < cb1; b += 64u) {
-                uint32_t byte = 0u;
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    const uint32_t r = 4u * b + j - seg_k0;           // rank inside the slice (>= 0: b >= ceil(seg_k0 / 4))
-                    const uint32_t s16 = s_idx[min(r, seg_cnt)];      // entries behind the slice are 0 (slack)
-                    const uint32_t code = ((uint32_t)stage[s16 >> 2] >> ((s16 & 3u) * 2u)) & 3u;
-                    byte |= (r < seg_cnt ? code : 0u) << (2u * j);
-                }
-                if (b + 1u == cb1) byte |= f_bits;
-                crow[b] = (uint8_t)byte;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            return;
-        }
         uint8_t *const row_out = lines ? a.out + toff : a.out + (j0 + n * row_step) * a.out_stride;
         const uint64_t lo_emit = 4ull * seg_k0;
         const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
@@ -206,19 +166,153 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     // two register buffers, the loop unrolled by two: the next row's loads are in flight while this row's text goes out
     // (three buffers, re-loaded three rows ahead, measured no better: 3.20-3.35 vs 3.03-3.20 ms on the config-5 geometry)
     v4u b0[kTilesPerSeg], b1[kTilesPerSeg];
-    uint32_t f0 = 0u, f1 = 0u;
     uint64_t t0 = 0ull, t1 = 0ull;
-    load_row(0ull, b0, f0, t0);
+    load_row(0ull, b0, t0);
     for (uint64_t n = 0;;) {
         landed(b0);
-        load_row(n + 1ull, b1, f1, t1);
-        emit_row(n, b0, f0, t0);
+        load_row(n + 1ull, b1, t1);
+        emit_row(n, b0, t0);
         if (++n == rows) break;
         landed(b1);
-        load_row(n + 1ull, b0, f0, t0);
-        emit_row(n, b1, f1, t1);
+        load_row(n + 1ull, b0, t0);
+        emit_row(n, b1, t1);
         if (++n == rows) break;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gt_compact_kernel — first pass of the two-pass path for sparse keeps on long records (capi.hip; BASELINE configs[4]).
+// Same block map, same table, same wide loads as gt_scan_pick_kernel, but instead of text the block writes its part of each
+// row's COMPACT record to a.out + j * a.out_stride: the K kept codes packed four to a byte exactly like a mode-0x02 record of
+// K samples (src/pfile.rs:171-175 applied here; :177-190 by the all-samples kernels in the second pass).  Byte b of a compact
+// record belongs to the segment that owns rank 4b: a block writes bytes ceil(k0/4) .. ceil(k1/4)-1 of its rank slice [k0, k1)
+// and fetches the up to three ranks behind k1 that share its last byte straight from the record (their samples live in later
+// segments) — no byte is written twice, nothing needs zeroing.
+//
+// This kernel is a pure record READER (125 000 bytes in, 1 250 out per row at 1 % kept), so the one thing that matters is that
+// its loads never wait for anything but loads.  gfx9 counts loads and stores in ONE in-order vmcnt, and the compiler cannot
+// count stores that sit in a loop or behind a branch: round 2's form — next row's loads, this row's picks and byte stores, wait
+// for the loads — compiled to `s_waitcnt vmcnt(0)` in front of every row, i.e. every row also waited for the acknowledgement of
+// the bytes it had just stored (1.02 ms per 5.2-GB chunk = 5.1 TB/s, while the same loads alone run at 6.3-6.4 TB/s:
+// tools/readbench.hip, profiles/r03_kernel_sweeps.md).  Here a row's compact bytes are parked in the wave's LDS out-stage and
+// leave ONE ROW LATER, right behind the wait and in front of the next loads: in program order nothing is ever younger than the
+// loads a wave waits for, so vmcnt(0) costs nothing.
+template <bool HAS_VIDX>
+__global__ __launch_bounds__(kThreads) void gt_compact_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups, uint32_t xcd_groups)
+{
+    __shared__ uint16_t s_idx[kCompactMaxSegCodes + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
+    __shared__ uint8_t s_out[kWaves][kCompactMaxSegCodes / 4u + 64u];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the XCD-aware block -> (segment, row group) map of gt_scan_pick_kernel: a row's 31 pieces leave through ONE L2
+    const bool xcd_map = blockIdx.x < xcd_groups * n_seg;
+    const uint32_t b_plain = blockIdx.x - xcd_groups * n_seg;
+    const uint32_t seg = xcd_map ? (blockIdx.x >> 3) % n_seg : b_plain % n_seg;
+    const uint32_t row_group = xcd_map ? ((blockIdx.x >> 3) / n_seg) * 8u + (blockIdx.x & 7u) : xcd_groups + b_plain / n_seg;
+    const uint32_t K = a.kept_count;
+    const uint32_t seg_k0 = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg]);
+    const uint32_t seg_cnt = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg + 1u]) - seg_k0;
+    const uint32_t R = a.record_size;
+    const uint64_t row_step = (uint64_t)row_groups * kWaves;
+    const uint64_t j0 = (uint64_t)row_group * kWaves + wave;
+    const uint64_t rows = j0 < (uint64_t)a.n_variants ? ((uint64_t)a.n_variants - j0 + row_step - 1ull) / row_step : 0ull;
+    if (seg_cnt == 0u) return;   // nothing of this segment is kept
+    // bytes of the compact record this block owns, and the ranks behind its slice that share its last byte
+    const uint32_t seg_k1 = seg_k0 + seg_cnt;
+    const uint32_t cb0 = (seg_k0 + 3u) >> 2, cb1 = (seg_k1 + 3u) >> 2;
+    if (cb0 == cb1) return;      // every rank of the slice sits in a byte an earlier segment owns
+    const uint32_t n_foreign = min((cb1 << 2) - seg_k1, K - seg_k1);   // 0 .. 3
+    uint32_t f_smp = 0u;         // lane i < n_foreign: sample of rank seg_k1 + i
+    if (lane < n_foreign) f_smp = a.kept_idx[seg_k1 + lane];
+    for (uint32_t r = tid; r < seg_cnt + 8u; r += (uint32_t)kThreads)
+        s_idx[r] = r < seg_cnt ? (uint16_t)(a.kept_idx[seg_k0 + r] - seg * kSegSamples) : (uint16_t)0;  // slack entries read as sample 0
+    __syncthreads();
+    if (rows == 0ull) return;
+
+    uint8_t *const stage = s_stage[wave];
+    uint8_t *const ostage = s_out[wave];
+    const uint32_t tile0 = seg * kTilesPerSeg;
+    const uint32_t tail_t = (R - 1u) >> 10;
+    const uint32_t tail_b = tail_t * 1024u + lane * 16u;
+    const uint32_t tail_off = min(tail_b, R - 16u);
+    const uint32_t tail_shift = tail_b + 16u <= R ? 0u : min(tail_b - (R - 16u), 16u);
+    auto load_row = [&](uint64_t n, v4u(&dst)[kTilesPerSeg], uint32_t &fbyte) {
+        const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
+        const uint8_t *__restrict__ rec = HAS_VIDX ? gathered_record(a, row) : a.records + row * a.record_stride;
+        const uint8_t *__restrict__ sub = rec + (uint64_t)tile0 * 1024u;
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) {
+            const uint8_t *src16 = tile0 + t < tail_t ? sub + lane * 16u + t * 1024u : rec + tail_off;
+            __builtin_memcpy(&dst[t], src16, 16);
+        }
+        if (lane < n_foreign) fbyte = rec[f_smp >> 2];  // the record byte of a rank behind the slice (a later segment's sample)
+    };
+    // row n's compact bytes, picked from the parked record bytes into the out-stage (lane <-> byte b = ranks 4b .. 4b+3)
+    auto pick_row = [&](const v4u(&w)[kTilesPerSeg], uint32_t fbyte) {
+#pragma unroll
+        for (uint32_t tile = 0; tile < kTilesPerSeg; tile++) {
+            v4u x = w[tile];
+            if (tile0 + tile == tail_t) {
+                uint64_t lo, hi;
+                window_halves(x, tail_shift, lo, hi);
+                x = v4u{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+            }
+            if (tile0 + tile <= tail_t) *reinterpret_cast<v4u *>(stage + tile * 1024u + lane * 16u) = x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the foreign ranks' codes, wave-uniform: rank seg_k1 + i sits at bits 2 * ((seg_k1 + i) & 3) of the last owned byte
+        uint32_t f_bits = 0u;
+        const uint32_t f_code = (fbyte >> ((f_smp & 3u) * 2u)) & 3u;
+        for (uint32_t i = 0; i < n_foreign; i++)
+            f_bits |= (uint32_t)__builtin_amdgcn_readlane((int)f_code, (int)i) << (2u * ((seg_k1 + i) & 3u));
+#pragma clang loop unroll(disable)
+        for (uint32_t b = cb0 + lane; b < cb1; b += 64u) {
+            uint32_t byte = 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t r = 4u * b + j - seg_k0;           // rank inside the slice (>= 0: b >= ceil(seg_k0 / 4))
+                const uint32_t s16 = s_idx[min(r, seg_cnt)];      // entries behind the slice are 0 (slack)
+                const uint32_t code = ((uint32_t)stage[s16 >> 2] >> ((s16 & 3u) * 2u)) & 3u;   // src/pfile.rs:171-175
+                byte |= (r < seg_cnt ? code : 0u) << (2u * j);
+            }
+            if (b + 1u == cb1) byte |= f_bits;
+            ostage[b - cb0] = (uint8_t)byte;   // (the same lane takes it out again: no cross-lane traffic through the out-stage)
+        }
+        // the stage is rewritten by the next row: this row's reads must have returned first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // the parked bytes of row n leave for HBM (one row after they were picked)
+    auto store_row = [&](uint64_t n) {
+        uint8_t *const crow = a.out + (j0 + n * row_step) * a.out_stride;
+#pragma clang loop unroll(disable)
+        for (uint32_t b = cb0 + lane; b < cb1; b += 64u) crow[b] = ostage[b - cb0];
+    };
+    auto landed = [&](const v4u(&w)[kTilesPerSeg]) {
+#pragma unroll
+        for (uint32_t t = 0; t < kTilesPerSeg; t++) asm volatile("" ::"v"(w[t].x), "v"(w[t].y), "v"(w[t].z), "v"(w[t].w));
+    };
+    v4u b0[kTilesPerSeg], b1[kTilesPerSeg];
+    uint32_t f0 = 0u, f1 = 0u;
+    load_row(0ull, b0, f0);
+    for (uint64_t n = 0;;) {
+        landed(b0);                       // vmcnt(0): only row n's loads (and long-gone stores) are outstanding
+        if (n != 0ull) store_row(n - 1ull);
+        load_row(n + 1ull, b1, f1);
+        pick_row(b0, f0);
+        if (++n == rows) break;
+        landed(b1);
+        store_row(n - 1ull);
+        load_row(n + 1ull, b0, f0);
+        pick_row(b1, f1);
+        if (++n == rows) break;
+    }
+    store_row(rows - 1ull);
 }
 
 }  // namespace
@@ -246,12 +340,20 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
     // two blocks per CU the pick kernel is ahead there too: 1.5 % kept 1.85 vs 1.99 ms, profiles/r02_kernel_sweeps.md).
     // Blocks per CU: the occupancy API says 3 (32 KiB table + 16 KiB of stages); from ~0.6 % kept upwards 2 measure the same or
     // better (+5-9 % at 1-3 % kept, level from 30 %), below that 3 do (the kernel is then a pure record reader).
-    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t, uint32_t);
-    if (compact)  // first pass of the two-pass path: a.out / a.out_stride address the compact records (ceil(K / 4) bytes per row)
-        kern = gathered(a) ? gt_scan_pick_kernel<true, true> : gt_scan_pick_kernel<false, true>;
-    else
-        kern = gathered(a) ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
-    const int preferred = !compact && (uint64_t)a.kept_count * 170ull >= (uint64_t)a.sample_count ? 2 : 0;
+    if (compact) {
+        // first pass of the two-pass path: a.out / a.out_stride address the compact records (ceil(K / 4) bytes per row)
+        if (sc.max_seg_count > kCompactMaxSegCodes) return hipErrorInvalidValue;  // (capi.hip takes the single pass then)
+        void (*ckern)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t) = gathered(a) ? gt_compact_kernel<true> : gt_compact_kernel<false>;
+        uint64_t groups = (uint64_t)resident_blocks(ckern, kThreads, num_cus, t, 2) / n_seg_eff;  // floor: never a partial second round; two blocks per CU (3: -1 %, 5: -6 %)
+        if (groups < 1ull) groups = 1ull;
+        if (groups > groups_needed) groups = groups_needed;
+        // one narrow window of rows (a record reader: banded -3 %, profiles/r02_kernel_sweeps.md)
+        const uint32_t xcd_groups = t.scan_xcd_map != 0 ? (uint32_t)(groups & ~7ull) : 0u;
+        hipLaunchKernelGGL(ckern, dim3((uint32_t)(groups * n_seg_eff)), dim3(kThreads), 0, stream, a, sc, n_seg_eff, (uint32_t)groups, xcd_groups);
+        return hipGetLastError();
+    }
+    void (*kern)(EmitArgs, ScanArgs, uint32_t, uint32_t, uint32_t, uint32_t) = gathered(a) ? gt_scan_pick_kernel<true> : gt_scan_pick_kernel<false>;
+    const int preferred = (uint64_t)a.kept_count * 170ull >= (uint64_t)a.sample_count ? 2 : 0;
     uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus, t, preferred) / n_seg_eff;  // floor: never a partial second round
     if (groups < 1ull) groups = 1ull;  // more segments than resident blocks (N > ~16 M samples): rounds are unavoidable
     if (groups > groups_needed) groups = groups_needed;
@@ -260,7 +362,7 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
     // Eight bands where the text dominates the traffic (>= 10 % kept: N = 500 000, 10 % kept 0.599 -> 0.626 of roofline, 50 % 0.589 ->
     // 0.593); one front where the launch is mostly a record reader (1 % kept, compact pass: 0.634 vs 0.614 banded; 0.3 % single pass:
     // 0.741 vs 0.693) — reads like the one narrow window, writes like several fronts (profiles/r02_kernel_sweeps.md)
-    const bool banded = !compact && (uint64_t)a.kept_count * 10ull >= (uint64_t)a.sample_count && groups % 8ull == 0ull && groups_needed >= 64ull * groups;
+    const bool banded = (uint64_t)a.kept_count * 10ull >= (uint64_t)a.sample_count && groups % 8ull == 0ull && groups_needed >= 64ull * groups;
     const uint32_t bands = banded ? 8u : 1u;   // (every band holds the same number of row groups)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, stream, a, sc, n_seg_eff, (uint32_t)groups, xcd_groups, bands);
     return hipGetLastError();

@@ -43,6 +43,9 @@ struct Tuning {
     int scan_xcd_map = 1;          // segment kernels: all blocks of a row group on one XCD (seam lines merge in one L2); 0 = plain map
     int scan_chunk_rows = 0;       // two-pass path: rows per chunk (0 = as many as the 64-MiB compact scratch holds; tests force small chunks)
     int scan_two_pass = 1;         // sparse keeps on long records: compact pass + all-samples pass (0 = single-pass segment kernel)
+    int rowpick_blocks_per_cu = 0; // row-owner kernel: cap on resident blocks per CU (0 = what the occupancy API says)
+    int scan_rowpick = 1;          // (1: row-owner compact pass + all-samples pass; 2: row-owner single pass; 0: segment compact pass)
+         // sparse keeps on long records, many rows: one wave per row, one pass (0 = the segment kernels / two passes)
     int runs_rows = 0;             // RUNS mode of the stream kernel: rows per work item (0 = as many as one wide load / one span holds)
 };
 
@@ -80,9 +83,20 @@ struct ScanArgs {
     const uint32_t *seg_rank;    // device; n_segments + 1 entries
     uint32_t max_seg_count;      // most kept samples in any one segment
 };
+// The compact pass takes segments with at most this many kept samples (a quarter of a segment; the two-pass band is <= 4.5 %
+// kept overall, so only a very clustered list has more in one segment: capi.hip then stays with the single-pass kernel)
+constexpr uint32_t kCompactMaxSegCodes = 4096u;
 // compact = true: write each row's COMPACT record (the K kept codes packed like a mode-0x02 record of K samples) to a.out + j * a.out_stride
 // instead of text: the first pass of the two-pass path for sparse keeps (capi.hip)
 hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t, int num_cus, hipStream_t stream, bool compact = false);
+
+// Sparse kept subsets on long records, one wave per ROW (gt_rowpick.hip): the whole kept list as the LDS table, the row's compact
+// record assembled in LDS segment by segment, its text written in one go.  Any strides / gathers / full lines.
+constexpr uint32_t kRowPickMaxKept = 16384u;
+bool gt_rowpick_applicable(const EmitArgs &a, int num_cus);   // what AUTO requires (incl. enough rows for every resident wave)
+// compact = true: the row's COMPACT record (ceil(K / 4) bytes at a.out + row * a.out_stride) instead of its text: first pass of the two-pass path
+uint32_t gt_rowpick_resident_waves(const EmitArgs &a, const Tuning &t, int num_cus, bool compact);   // rows of one round (0: not applicable)
+hipError_t launch_gt_rowpick(const EmitArgs &a, const ScanArgs &sc, const Tuning &t, int num_cus, hipStream_t stream, bool compact = false);
 
 // kept subsets on short records (N <= 4096): output-driven pick through the kept list, no compaction (gt_pick.hip)
 bool gt_pick_applicable(const EmitArgs &a);

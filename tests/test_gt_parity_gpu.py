@@ -32,6 +32,8 @@ def kernels_for(subset: bool, dense: bool, n: int = 0, k: int = 0):
         ks.append(_capi.KERNEL_SCAN)
     if dense and 61 <= n <= 4096 and (k >= 1 if subset else True):
         ks.append(_capi.KERNEL_PICK)  # short records: kept subset through the table, or all samples (identity)
+    if subset and n >= 61 and 1 <= k <= 16384:
+        ks.append(_capi.KERNEL_ROWPICK)  # one wave per row (any strides)
     return ks
 
 
@@ -187,7 +189,7 @@ def test_subset_with_strides_offsets_and_gather():
     dense = np.concatenate([recs[5 + i * rstride : 5 + i * rstride + r] for i in range(vfile)])
     want = oracle.decode_emit(dense, len(vidx), n, kept_idx=kept, variant_idx=vidx).reshape(len(vidx), -1)
     k = kept.size
-    for kern in kernels_for(True, False, n):
+    for kern in kernels_for(True, False, n, k):
         got, _ = run_engine(recs, len(vidx), n, kept=kept, kernel=kern, record_stride=rstride, out_stride=4 * k + 1 + 6,
                             variant_idx=vidx, out_offset=3, records_offset=5)
         exp = expect_buffer(want, len(vidx), k, 4 * k + 1 + 6, 3, got.size)
@@ -406,6 +408,69 @@ def test_launches_of_one_ctx_on_different_streams_overlap():
         out = eng.decode_emit(recs[0], v)
         eng.wait()
         assert out.cpu().numpy().tobytes() == oracle.decode_emit(recs[0][: v * r].cpu().numpy(), v, n).tobytes()
+
+
+@pytest.mark.parametrize("n,k,v", [(40_000, 400, 9_001), (70_001, 1_900, 8_200), (16_385, 300, 8_193), (100_003, 4_001, 8_500)])
+@pytest.mark.parametrize("mode", ["gt", "lines", "gather_padded"])
+def test_row_owner_kernel_sparse_keeps_many_rows(n, k, v, mode):
+    """BASELINE configs[4]'s band with enough rows for every resident wave (AUTO -> gt_rowpick.hip: one wave per row, the row's
+    compact record assembled in LDS segment by segment — bytes that straddle two segments, empty segments, the record's tail
+    tile — and its text written in one go): GT segments, full lines (the kernel writes the prefixes itself), and a gathered,
+    padded layout; AUTO and the forced kernel agree with the oracle byte for byte, sentinels untouched."""
+    rng = np.random.default_rng(n + k)
+    kept = np.sort(rng.choice(n, size=k, replace=False)).astype(np.uint32)
+    if n == 70_001:
+        kept = np.sort(np.concatenate([rng.choice(20_000, size=k - 3, replace=False), [n - 1, n - 2, 49_152]])).astype(np.uint32)  # empty segments 1 and 2, the last sample
+        kept = np.unique(kept)
+        k = len(kept)
+    r = oracle.variant_record_size(n)
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        if mode == "gather_padded":
+            stride = r + 7
+            v_file = v + 50
+            base = eng.synth_records(v_file, first_variant=3, record_stride=stride)
+            vidx = np.sort(rng.choice(v_file, size=v, replace=False)).astype(np.int32)
+            host = base.cpu().numpy()
+            dense = np.concatenate([host[i * stride : i * stride + r] for i in vidx])
+            want = oracle.decode_emit(dense, v, n, kept_idx=kept).reshape(v, -1)
+            ostride = 4 * k + 1 + 5
+            for kern in (_capi.KERNEL_ROWPICK,):
+                out = torch.full((v * ostride + 16,), SENTINEL, dtype=torch.uint8, device=DEV)
+                eng.decode_emit(base, v, record_stride=stride, variant_idx=torch.from_numpy(vidx).to(DEV), out=out, out_stride=ostride, kernel=kern)
+                eng.wait()
+                got = out.cpu().numpy()
+                exp = expect_buffer(want, v, k, ostride, 0, got.size)
+                assert (got == exp).all(), f"kernel {kern}"
+            return
+        recs = eng.synth_records(v, first_variant=17)
+        host = recs[: v * r].cpu().numpy()
+        if mode == "gt":
+            want = oracle.decode_emit(host, v, n, kept_idx=kept).tobytes()
+            for kern in (_capi.KERNEL_AUTO, _capi.KERNEL_ROWPICK):
+                out = torch.full((5 + v * (4 * k + 1) + 16,), SENTINEL, dtype=torch.uint8, device=DEV)
+                for mode_knob in ((1, -1, 2) if kern == _capi.KERNEL_AUTO else (1,)):   # AUTO: row-owner compact pass, segment compact pass, row-owner single pass
+                    eng.tune(_capi.KNOB_SCAN_ROWPICK, mode_knob)
+                    out.fill_(SENTINEL)
+                    eng.decode_emit(recs, v, out=out, kernel=kern, out_offset=5)
+                    eng.wait()
+                    got = out.cpu().numpy()
+                    assert (got[:5] == SENTINEL).all() and (got[5 + len(want) :] == SENTINEL).all(), f"kernel {kern} knob {mode_knob} wrote outside"
+                    assert got[5 : 5 + len(want)].tobytes() == want, f"kernel {kern} knob {mode_knob}"
+                eng.tune(_capi.KNOB_SCAN_ROWPICK, 1)
+        else:
+            plen = rng.integers(0, 70, size=v).astype(np.int64)
+            poff = np.concatenate([[0], np.cumsum(plen)]).astype(np.int64)
+            loff = np.concatenate([[0], np.cumsum(plen + 4 * k + 1)]).astype(np.int64)
+            blob = rng.integers(65, 91, size=int(poff[-1]) + 1, dtype=np.uint8)
+            want = oracle.emit_lines(host, v, n, blob, poff.astype(np.uint64), loff.astype(np.uint64), kept_idx=kept).tobytes()
+            d_blob, d_poff, d_loff = (torch.from_numpy(x).to(DEV) for x in (blob, poff, loff))
+            for kern in (_capi.KERNEL_AUTO, _capi.KERNEL_ROWPICK):
+                out = torch.full((3 + int(loff[-1]) + 16,), SENTINEL, dtype=torch.uint8, device=DEV)
+                eng.emit_lines(recs, v, d_blob, d_poff, d_loff, int(plen.max()), out[3:], kernel=kern)
+                eng.wait()
+                got = out.cpu().numpy()
+                assert (got[:3] == SENTINEL).all() and (got[3 + len(want) :] == SENTINEL).all(), f"kernel {kern} wrote outside"
+                assert got[3 : 3 + len(want)].tobytes() == want, f"kernel {kern}"
 
 
 @pytest.mark.parametrize("lines", [False, True])
@@ -881,13 +946,14 @@ def test_config3_full_size_100k_by_500k(v):
 
 
 @pytest.mark.parametrize("v", [100_000, 125_000])
-@pytest.mark.parametrize("path", ["two_pass", "segment_xcd", "segment_plain"])
+@pytest.mark.parametrize("path", ["two_pass", "two_pass_segment_compact", "row_owner_single_pass", "segment_xcd", "segment_plain"])
 def test_config5_geometry_500k_samples_keep_1pct(path, v):
     """BASELINE config 5's per-GPU geometry in ONE launch: 100 000 variants x 500 000 samples and the
     125 000-variant shard each of 8 GPUs owns (12.5 / 15.6 GB of records, offsets beyond 2^32), the 1 %
     splitmix keep mask of SURVEY 8(d) (4 940 kept -> 19 761-byte rows, 1.98 / 2.47 GB of text).
-    AUTO (two passes: compact records, then the row-item stream kernel on them) and the single-pass segment kernel with the
-    XCD-aware and the plain block map: LF / TAB / slash columns over the whole buffer, byte
+    AUTO (two passes: compact records — from the row-owner kernel, or from the segment kernel — then the row-item stream
+    kernel on them), the row-owner kernel writing text in one pass, and the single-pass segment kernel with the XCD-aware and
+    the plain block map: LF / TAB / slash columns over the whole buffer, byte
     equality with the oracle on rows from the start, the reference's u32-wrap boundary, the middle and
     the end, and equality of the three paths' whole outputs through a checksum of checksums."""
     n = 500_000
@@ -899,8 +965,9 @@ def test_config5_geometry_500k_samples_keep_1pct(path, v):
     row = 4 * k + 1
     with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
         eng.tune(_capi.KNOB_SCAN_XCD_MAP, -1 if path == "segment_plain" else 1)
+        eng.tune(_capi.KNOB_SCAN_ROWPICK, {"two_pass_segment_compact": -1, "row_owner_single_pass": 2}.get(path, 1))
         recs = eng.synth_records(v)
-        out = eng.decode_emit(recs, v, kernel=_capi.KERNEL_AUTO if path == "two_pass" else _capi.KERNEL_SCAN)
+        out = eng.decode_emit(recs, v, kernel=_capi.KERNEL_SCAN if path.startswith("segment") else _capi.KERNEL_AUTO)
         eng.wait()
         assert out.numel() == v * row
         assert bool((out[row - 1 :: row] == 10).all())

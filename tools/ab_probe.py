@@ -21,7 +21,7 @@ import pgen_rs_amd
 from pgen_rs_amd import _capi
 
 KERNELS = {"auto": _capi.KERNEL_AUTO, "rows": _capi.KERNEL_ROWS, "flat": _capi.KERNEL_FLAT, "scan": _capi.KERNEL_SCAN,
-           "wide": _capi.KERNEL_WIDE, "pick": _capi.KERNEL_PICK, "runs": _capi.KERNEL_RUNS}
+           "wide": _capi.KERNEL_WIDE, "pick": _capi.KERNEL_PICK, "runs": _capi.KERNEL_RUNS, "rowpick": _capi.KERNEL_ROWPICK}
 KNOBS = {k[len("KNOB_"):].lower(): getattr(_capi, k) for k in dir(_capi) if k.startswith("KNOB_")}
 
 
