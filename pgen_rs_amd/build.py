@@ -76,7 +76,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
 
 HOST_DIR = PKG_DIR / "host"
 HOST_BIN = PKG_DIR / "pgen-hip"
-HOST_SOURCES = ["cli.cpp", "pfile.cpp", "csvlite.cpp", "expr.cpp"]
+HOST_SOURCES = ["cli.cpp", "pfile.cpp", "csvlite.cpp", "expr.cpp", "bgzf.cpp"]
 
 
 def build_host(force: bool = False, verbose: bool = False) -> Path:
@@ -85,7 +85,7 @@ def build_host(force: bool = False, verbose: bool = False) -> Path:
     deps = srcs + sorted(HOST_DIR.glob("*.h")) + [REPO_ROOT / "include" / "pgen_hip.h", HIP_LIB, Path(__file__)]
     if force or _stale(HOST_BIN, deps):
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-I", str(REPO_ROOT / "include"),
-               "-o", str(HOST_BIN), *map(str, srcs), "-L", str(PKG_DIR), "-lpgen_hip", "-Wl,-rpath,$ORIGIN"]
+               "-o", str(HOST_BIN), *map(str, srcs), "-L", str(PKG_DIR), "-lpgen_hip", "-lz", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         _run(cmd, HOST_DIR)

@@ -5,7 +5,8 @@
 //   pgen-hip filter <PFILE_PREFIX> [--include-var <EXPR>] [--include-sam <EXPR>] [-o|--out <FILE>]
 //
 // Additions (opt-in, not in the reference): --gpus <N>, --block-mib <M>, --filter-threads <T>, --stats, --dry-run
-// (filter: write the VCF header only and report the body geometry; needs no GPU).
+// (filter: write the VCF header only and report the body geometry; needs no GPU); BGZF output (`-o x.vcf.gz` or --bgzf,
+// --bgzf-level <1-9>, --compress-threads <T>) and `pgen-hip bgzf <IN> <OUT>`, the same writer on a file.
 // Exit codes: 0 ok; 2 usage error (clap's code); 101 where the reference would panic.
 #include <cstdio>
 #include <cstdlib>
@@ -15,12 +16,77 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <unistd.h>
+
+#include "bgzf.h"
 #include "expr.h"
 #include "pfile.h"
 
 using namespace pgenhost;
 
 namespace {
+
+struct Fd {
+    int fd;
+    ~Fd()
+    {
+        if (fd >= 0) close(fd);
+    }
+};
+
+void close_or_throw(Fd &f, const std::string &path)
+{
+    const int fd = f.fd;
+    f.fd = -1;
+    if (close(fd) != 0) throw PfileError("close " + path + ": " + std::strerror(errno));
+}
+
+// --dry-run: the VCF header alone, as text or as a complete BGZF file (header members + EOF marker)
+void write_header_only(const std::string &out_file, const std::string &header, bool bgzf, int level)
+{
+    Fd f{open(out_file.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644)};
+    if (f.fd < 0) throw PfileError("create " + out_file + ": " + std::strerror(errno));
+    if (bgzf) {
+        BgzfWriter w(f.fd, out_file, level, 1);
+        w.write(header.data(), header.size());
+        w.finish();
+    } else {
+        const char *p = header.data();
+        for (size_t left = header.size(); left;) {
+            ssize_t n = write(f.fd, p, left);
+            if (n < 0 && errno == EINTR) continue;
+            if (n <= 0) throw PfileError("write " + out_file + ": " + std::strerror(errno));
+            p += n;
+            left -= (size_t)n;
+        }
+    }
+    close_or_throw(f, out_file);
+}
+
+void bgzf_file(const std::string &in, const std::string &out, int level, unsigned threads, size_t chunk)
+{
+    Fd i{open(in.c_str(), O_RDONLY)};
+    if (i.fd < 0) throw PfileError("open " + in + ": " + std::strerror(errno));
+    Fd o{open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644)};
+    if (o.fd < 0) throw PfileError("create " + out + ": " + std::strerror(errno));
+    BgzfWriter w(o.fd, out, level, threads);
+    std::vector<uint8_t> buf(chunk);
+    for (;;) {
+        size_t got = 0;
+        while (got < buf.size()) {
+            ssize_t r = read(i.fd, buf.data() + got, buf.size() - got);
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0) throw PfileError("read " + in + ": " + std::strerror(errno));
+            if (r == 0) break;
+            got += (size_t)r;
+        }
+        if (!got) break;
+        w.write(buf.data(), got);
+    }
+    w.finish();
+    close_or_throw(o, out);
+}
 
 const char *kUsage =
     "Usage: pgen-hip <COMMAND>\n\n"
@@ -30,7 +96,9 @@ const char *kUsage =
     "  help    Print this message\n\n"
     "query  <PFILE_PREFIX> -f, --fstring <QUERY_FSTRING> [-i, --include <QUERY>] [-s, --samples]\n"
     "filter <PFILE_PREFIX> [--include-var <VAR_QUERY>] [--include-sam <SAM_QUERY>] [-o, --out <OUT_FILE>]\n"
-    "       [--gpus <N>] [--shards <S>] [--block-mib <M>] [--write-threads <T>] [--read-threads <T>] [--filter-threads <T>] [--stats] [--dry-run]\n";
+    "       [--gpus <N>] [--shards <S>] [--block-mib <M>] [--write-threads <T>] [--read-threads <T>] [--filter-threads <T>] [--stats] [--dry-run]\n"
+    "       [--bgzf] [--bgzf-level <1-9>] [--compress-threads <T>]   (BGZF `.vcf.gz`; implied by an OUT_FILE ending in .gz)\n"
+    "bgzf   <IN_FILE> <OUT_FILE> [--level <1-9>] [--threads <T>] [--chunk-mib <M>]\n";
 
 [[noreturn]] void usage_error(const std::string &msg)
 {
@@ -157,11 +225,15 @@ int main(int argc, char **argv)
             return 0;
         }
         if (cmd == "filter") {  // src/main.rs:114-124
-            Args a = parse(argc, argv, 2, {{"include-var", 0}, {"include-sam", 0}, {"out", 'o'}, {"gpus", 0}, {"shards", 0}, {"block-mib", 0}, {"write-threads", 0}, {"read-threads", 0}, {"filter-threads", 0}},
-                           {{"stats", 0}, {"dry-run", 0}});
+            Args a = parse(argc, argv, 2, {{"include-var", 0}, {"include-sam", 0}, {"out", 'o'}, {"gpus", 0}, {"shards", 0}, {"block-mib", 0}, {"write-threads", 0}, {"read-threads", 0}, {"filter-threads", 0}, {"bgzf-level", 0}, {"compress-threads", 0}},
+                           {{"stats", 0}, {"dry-run", 0}, {"bgzf", 0}});
             if (a.positional.size() != 1) usage_error("the following required arguments were not provided: <PFILE_PREFIX>");
             const Pfile pfile = Pfile::from_prefix(a.positional[0]);
-            const std::string out_file = a.get("out").value_or(pfile.pfile_prefix + ".pgen-rs.vcf");  // :121-122
+            auto ends_with = [](const std::string &x, const char *suffix) { const size_t n = std::strlen(suffix); return x.size() >= n && x.compare(x.size() - n, n, suffix) == 0; };
+            const bool bgzf = a.has("bgzf") || (a.get("out") && ends_with(*a.get("out"), ".gz"));
+            const std::string out_file = a.get("out").value_or(pfile.pfile_prefix + (bgzf ? ".pgen-rs.vcf.gz" : ".pgen-rs.vcf"));  // :121-122
+            const int bgzf_level = a.get("bgzf-level") ? std::atoi(a.get("bgzf-level")->c_str()) : 6;
+            if (bgzf_level < 1 || bgzf_level > 9) usage_error("--bgzf-level takes 1 .. 9");
             const int filter_threads = a.get("filter-threads") ? std::max(1, std::atoi(a.get("filter-threads")->c_str())) : 0;
             if (a.has("dry-run")) {
                 // header + geometry only: the plumbing of BASELINE config 1 without touching a GPU
@@ -173,10 +245,7 @@ int main(int argc, char **argv)
                 const auto vars = Pfile::filter_metadata(pvar_reader, a.get("include-var"), filter_threads);
                 const auto sams = Pfile::filter_metadata(psam_reader, a.get("include-sam"), filter_threads);
                 const std::string header = pfile.vcf_header(sams, sam_header);
-                FILE *f = std::fopen(out_file.c_str(), "wb");
-                if (!f) throw PfileError("create " + out_file + ": " + std::strerror(errno));
-                std::fwrite(header.data(), 1, header.size(), f);
-                std::fclose(f);
+                write_header_only(out_file, header, bgzf, bgzf_level);
                 unsigned long long prefix = 0;
                 for (const auto &v : vars) {
                     prefix += 2;
@@ -189,6 +258,9 @@ int main(int argc, char **argv)
             }
             OutputOptions opt;
             opt.filter_threads = filter_threads;
+            opt.bgzf = bgzf;
+            opt.bgzf_level = bgzf_level;
+            if (auto c = a.get("compress-threads")) opt.compress_threads = std::max(1, std::atoi(c->c_str()));
             if (auto g = a.get("gpus")) opt.n_gpus = std::max(1, std::atoi(g->c_str()));
             if (auto sh = a.get("shards")) opt.n_shards = std::max(1, std::atoi(sh->c_str()));
             if (auto w = a.get("write-threads")) opt.write_threads = std::max(1, std::atoi(w->c_str()));
@@ -198,10 +270,21 @@ int main(int argc, char **argv)
             if (a.has("stats")) {
                 std::fprintf(stderr,
                              "{\"variants_kept\": %llu, \"samples_kept\": %llu, \"header_bytes\": %llu, \"body_bytes\": %llu, "
-                             "\"seconds_filter\": %.6f, \"seconds_body\": %.6f, \"seconds_kernel\": %.6f}\n",
+                             "\"file_bytes\": %llu, \"seconds_filter\": %.6f, \"seconds_body\": %.6f, \"seconds_kernel\": %.6f}\n",
                              (unsigned long long)st.variants, (unsigned long long)st.samples_kept, (unsigned long long)st.header_bytes,
-                             (unsigned long long)st.body_bytes, st.seconds_filter, st.seconds_body, st.seconds_kernel);
+                             (unsigned long long)st.body_bytes, (unsigned long long)st.file_bytes, st.seconds_filter, st.seconds_body, st.seconds_kernel);
             }
+            return 0;
+        }
+        if (cmd == "bgzf") {
+            // not in the reference: the BGZF writer of `filter ... -o x.vcf.gz` applied to a file (what `bgzip -c IN > OUT` does)
+            Args a = parse(argc, argv, 2, {{"level", 0}, {"threads", 0}, {"chunk-mib", 0}}, {});
+            if (a.positional.size() != 2) usage_error("bgzf <IN_FILE> <OUT_FILE> [--level <1-9>] [--threads <T>] [--chunk-mib <M>]");
+            const int level = a.get("level") ? std::atoi(a.get("level")->c_str()) : 6;
+            if (level < 1 || level > 9) usage_error("--level takes 1 .. 9");
+            const unsigned threads = (unsigned)std::max(1, std::atoi(a.get("threads").value_or("8").c_str()));
+            const size_t chunk = (size_t)std::max(1, std::atoi(a.get("chunk-mib").value_or("64").c_str())) << 20;
+            bgzf_file(a.positional[0], a.positional[1], level, threads, chunk);
             return 0;
         }
         if (cmd == "synth") {
@@ -213,7 +296,7 @@ int main(int argc, char **argv)
             synth_pfile(a.positional[0], (uint32_t)std::strtoul(a.get("variants")->c_str(), nullptr, 10),
                         (uint32_t)std::strtoul(a.get("samples")->c_str(), nullptr, 10),
                         (uint32_t)std::strtoul(a.get("keep-modulus").value_or("100").c_str(), nullptr, 10),
-                        std::strtoull(a.get("seed").value_or("1346847054").c_str(), nullptr, 10));
+                        std::strtoull(a.get("seed").value_or("1346848078").c_str(), nullptr, 10));  // 0x5047454E "PGEN": seed_data of SURVEY.md 8(d) (round 2 had a typo here)
             return 0;
         }
         usage_error("unrecognized subcommand '" + cmd + "'");

@@ -18,6 +18,7 @@
 #include <thread>
 
 #include "../../include/pgen_hip.h"
+#include "bgzf.h"
 #include "expr.h"
 
 namespace pgenhost {
@@ -398,7 +399,45 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
         guard.fd = -1;
         if (close(cfd) != 0) throw PfileError("close " + filename + ": " + std::strerror(errno));
     };
-    pwrite_exact(fd, header.data(), header.size(), 0, filename);  // :139-146
+    const unsigned n_compress = (unsigned)(opt.compress_threads > 0 ? opt.compress_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
+    if (opt.bgzf) {
+        BgzfWriter hw(fd, filename, opt.bgzf_level, 1);
+        hw.write(header.data(), header.size());   // its own BGZF member(s); the body's members follow
+        st.file_bytes = hw.bytes_out();
+    } else {
+        pwrite_exact(fd, header.data(), header.size(), 0, filename);  // :139-146
+    }
+    // BGZF: every member is independent, so the shards' streams simply follow each other; shard 0 appends to the file itself, the
+    // others to temporary files that are appended in shard order at the end (one device: no temporary file)
+    auto shard_tmp = [&](int g) { return filename + ".shard" + std::to_string(g) + ".tmp"; };
+    auto finish_bgzf = [&](int n_shards) {
+        std::vector<uint8_t> buf(8u << 20);
+        for (int g = 1; g < n_shards; g++) {
+            const std::string tmp = shard_tmp(g);
+            int tfd = open(tmp.c_str(), O_RDONLY);
+            if (tfd < 0) continue;   // a shard without variants wrote nothing
+            for (;;) {
+                ssize_t r = read(tfd, buf.data(), buf.size());
+                if (r < 0 && errno == EINTR) continue;
+                if (r < 0) { close(tfd); throw PfileError("read " + tmp + ": " + std::strerror(errno)); }
+                if (r == 0) break;
+                const uint8_t *p = buf.data();
+                for (size_t left = (size_t)r; left;) {
+                    ssize_t w = write(fd, p, left);
+                    if (w < 0 && errno == EINTR) continue;
+                    if (w <= 0) { close(tfd); throw PfileError("write " + filename + ": " + std::strerror(errno)); }
+                    p += w;
+                    left -= (size_t)w;
+                }
+                st.file_bytes += (uint64_t)r;
+            }
+            close(tfd);
+            unlink(tmp.c_str());
+        }
+        BgzfWriter ew(fd, filename, opt.bgzf_level, 1);
+        ew.finish();
+        st.file_bytes += ew.bytes_out();
+    };
 
     // ---- geometry of the body (:156-192): line j = prefix_j + K x "\tA/B" + "\n"
     const uint32_t N = num_samples;
@@ -433,7 +472,9 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     st.samples_kept = K;
     st.header_bytes = header.size();
     st.body_bytes = file_off[V];
+    if (!opt.bgzf) st.file_bytes = st.header_bytes + st.body_bytes;
     if (V == 0) {
+        if (opt.bgzf) finish_bgzf(0);
         close_checked();
         return st;
     }
@@ -447,6 +488,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     std::mutex err_mu;
     std::string err;
     std::vector<double> kernel_s((size_t)G, 0.0);
+    std::vector<uint64_t> shard_out((size_t)G, 0);   // BGZF: compressed bytes per shard
     const std::string pgen = pgen_path();
 
     // Per device: two buffer sets, each with its own ctx/stream.  The producer (this thread) reads
@@ -468,6 +510,15 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
             int pfd = open(pgen.c_str(), O_RDONLY);  // :149 (unbuffered on purpose, :150-152)
             if (pfd < 0) throw PfileError("open " + pgen + ": " + std::strerror(errno));
             FdGuard pg{pfd};
+            // BGZF: this shard's ordered, parallel deflate writer (shard 0: the output file behind the header; others: a temporary file)
+            int zfd = -1;
+            if (opt.bgzf) {
+                zfd = g == 0 ? fd : open(shard_tmp(g).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+                if (zfd < 0) throw PfileError("create " + shard_tmp(g) + ": " + std::strerror(errno));
+            }
+            FdGuard zg{g == 0 ? -1 : zfd};
+            std::unique_ptr<BgzfWriter> zw;
+            if (opt.bgzf) zw.reset(new BgzfWriter(zfd, g == 0 ? filename : shard_tmp(g), opt.bgzf_level, std::max(1u, n_compress / (unsigned)std::max(1, std::min(G, n_use)))));
             // variants per block: bounded by the text budget — and by the same budget of RECORD bytes, so that a run that keeps few
             // samples (little text per record) still moves in several blocks and its file reads overlap the copies and the kernel
             const uint64_t max_line = max_prefix + 4ull * K + 1ull;
@@ -521,7 +572,9 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                         // every line has a known length, so ranges land at precomputed offsets in any order
                         const uint64_t file_pos = header.size() + file_off[job.b0];
                         const uint8_t *text = static_cast<const uint8_t *>(B.h_text);
-                        if (n_writers <= 1 || job.bytes < (8ull << 20)) {
+                        if (zw) {
+                            zw->write(text, (size_t)job.bytes);   // blocks arrive in order: the members are appended in order
+                        } else if (n_writers <= 1 || job.bytes < (8ull << 20)) {
                             pwrite_exact(fd, text, (size_t)job.bytes, file_pos, filename);
                         } else {
                             std::vector<std::thread> ws;
@@ -660,6 +713,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
             }
             if (consumer.joinable()) consumer.join();
             if (!consumer_err.empty()) throw PfileError(consumer_err);
+            if (zw) shard_out[(size_t)g] = zw->bytes_out();
         } catch (const std::exception &e) {
             std::lock_guard<std::mutex> lk(err_mu);
             if (err.empty()) err = e.what();
@@ -669,7 +723,15 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     for (int g = 1; g < G; g++) threads.emplace_back(worker, g);
     worker(0);
     for (auto &t : threads) t.join();
-    if (!err.empty()) throw PfileError(err);
+    if (!err.empty()) {
+        if (opt.bgzf)
+            for (int g = 1; g < G; g++) unlink(shard_tmp(g).c_str());
+        throw PfileError(err);
+    }
+    if (opt.bgzf) {
+        st.file_bytes += shard_out[0];
+        finish_bgzf(G);
+    }
     close_checked();
     st.seconds_body = now_s() - t_body;
     st.seconds_kernel = *std::max_element(kernel_s.begin(), kernel_s.end());

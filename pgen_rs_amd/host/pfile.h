@@ -29,12 +29,16 @@ struct OutputOptions {
                                                // keeping 20 samples: pinning the staging buffers costs more than bigger launches give (profiles/r02_e2e.md)
     int write_threads = 1;                  // parallel pwrite()s per block and device
     int read_threads = 4;                   // parallel pread()s of one run of consecutive records (runs of >= 64 MiB)
+    bool bgzf = false;                      // write BGZF (`.vcf.gz`) instead of plain text
+    int bgzf_level = 6;                     // zlib level of the BGZF members (bgzip's default)
+    int compress_threads = 0;               // deflate threads per device shard (0 = the host's cores, at most 32)
     int filter_threads = 0;                 // pieces the metadata walk is cut into (0 = by file size and host cores, 1 = serial like the reference)
     bool verbose = false;
 };
 
 struct OutputStats {
-    uint64_t variants = 0, samples_kept = 0, header_bytes = 0, body_bytes = 0;
+    uint64_t variants = 0, samples_kept = 0, header_bytes = 0, body_bytes = 0;   // header / body: bytes of VCF text
+    uint64_t file_bytes = 0;                                                     // what the output file holds (BGZF: compressed)
     double seconds_filter = 0, seconds_body = 0, seconds_kernel = 0;
 };
 

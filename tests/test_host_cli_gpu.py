@@ -195,3 +195,44 @@ def test_variable_width_file_compressed_record_exits_101(vw_pfile, tmp_path):
     assert p.returncode == 101 and b"stored compressed" in p.stderr
     q = run("query", str(vw_pfile), "-i", 'RTYPE != "0"', "-f", "ID")     # metadata queries never touch the records
     assert q.returncode == 0 and q.stdout.startswith(b"v")
+
+
+# ---- BGZF (`.vcf.gz`) output (format parity unpinned: the reference writes none) -----------------------
+def test_bgzf_output_round_trips_to_the_plain_file(basic1, tmp_path):
+    """`-o x.vcf.gz`: the same bytes as the plain file once inflated (python's gzip: an independent inflater), a BGZF EOF marker
+    at the end, every member <= 64 KiB; one shard, several shards (shards > 0 go through temporary files that are appended in
+    order), small blocks, and the `--bgzf` flag with the default output name."""
+    import gzip
+
+    from test_bgzf import check_bgzf
+
+    want = expected_vcf(basic1, var_pred=lambda r: r[b"ALT"] == b"G")
+    for i, extra in enumerate((["--block-mib", "64"], ["--shards", "3", "--block-mib", "4"], ["--block-mib", "1", "--bgzf-level", "1", "--compress-threads", "3"])):
+        out = tmp_path / f"g{i}.vcf.gz"
+        p = run("filter", str(basic1), "--include-var", 'ALT=="G"', "-o", str(out), "--stats", *extra)
+        assert p.returncode == 0, p.stderr
+        check_bgzf(out, want)
+        assert not list(tmp_path.glob("*.tmp")), "a shard's temporary file was left behind"
+        import json
+
+        stats = json.loads(p.stderr.decode().strip().splitlines()[-1])
+        assert stats["file_bytes"] == out.stat().st_size and stats["header_bytes"] + stats["body_bytes"] == len(want)
+        assert out.stat().st_size < len(want) // 4
+    p = run("filter", str(basic1), "--include-var", 'ID == "rs8100066"', "--include-sam", 'IID == "NA20900"', "--bgzf")
+    assert p.returncode == 0, p.stderr
+    default = Path(str(basic1) + ".pgen-rs.vcf.gz")
+    assert gzip.decompress(default.read_bytes()) == expected_vcf(basic1, var_pred=lambda r: r[b"ID"] == b"rs8100066", sam_pred=lambda r: r[b"IID"] == b"NA20900")
+    default.unlink()
+
+
+def test_bgzf_lines_longer_than_a_member(tmp_path):
+    """20 011 samples: every body line is 80 KB, longer than a BGZF member's 65 280 bytes of input — lines straddle members."""
+    from test_bgzf import check_bgzf
+
+    pfx = tmp_path / "wide"
+    assert run("synth", str(pfx), "--variants", "700", "--samples", "20011").returncode == 0
+    plain, gz = tmp_path / "w.vcf", tmp_path / "w.vcf.gz"
+    assert run("filter", str(pfx), "-o", str(plain)).returncode == 0
+    assert plain.read_bytes() == expected_vcf(pfx)
+    assert run("filter", str(pfx), "-o", str(gz), "--block-mib", "8").returncode == 0
+    check_bgzf(gz, plain.read_bytes())

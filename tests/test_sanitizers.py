@@ -27,8 +27,8 @@ def asan_cli(tmp_path_factory):
     d = tmp_path_factory.mktemp("asan")
     exe = d / "pgen-hip-asan"
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-pthread",
-           "-I", str(REPO / "include"), "-o", str(exe), *[str(HOST / f) for f in ("cli.cpp", "pfile.cpp", "csvlite.cpp", "expr.cpp")],
-           "-L", str(REPO / "pgen_rs_amd"), "-lpgen_hip", f"-Wl,-rpath,{REPO / 'pgen_rs_amd'}"]
+           "-I", str(REPO / "include"), "-o", str(exe), *[str(HOST / f) for f in ("cli.cpp", "pfile.cpp", "csvlite.cpp", "expr.cpp", "bgzf.cpp")],
+           "-L", str(REPO / "pgen_rs_amd"), "-lpgen_hip", "-lz", f"-Wl,-rpath,{REPO / 'pgen_rs_amd'}"]
     p = subprocess.run(cmd, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     return exe
@@ -73,8 +73,8 @@ def test_parallel_metadata_filter_under_asan_and_tsan(asan_cli, tmp_path):
 
     tsan = tmp_path / "pgen-hip-tsan"
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-I", str(REPO / "include"), "-o", str(tsan),
-           *[str(HOST / f) for f in ("cli.cpp", "pfile.cpp", "csvlite.cpp", "expr.cpp")],
-           "-L", str(REPO / "pgen_rs_amd"), "-lpgen_hip", f"-Wl,-rpath,{REPO / 'pgen_rs_amd'}"]
+           *[str(HOST / f) for f in ("cli.cpp", "pfile.cpp", "csvlite.cpp", "expr.cpp", "bgzf.cpp")],
+           "-L", str(REPO / "pgen_rs_amd"), "-lpgen_hip", "-lz", f"-Wl,-rpath,{REPO / 'pgen_rs_amd'}"]
     p = subprocess.run(cmd, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")

@@ -15,5 +15,9 @@ wc -c $D/two.vcf
 echo "== filter keep-all (README.md:178-183 shape)"; time $CLI filter $D/chr22 -o $D/all.vcf --stats
 wc -c $D/all.vcf; sha256sum $D/all.vcf | cut -c1-16
 rm -f $D/all.vcf
+echo "== filter keep-all -> BGZF (.vcf.gz), level 6 / level 1"; time $CLI filter $D/chr22 -o $D/all.vcf.gz --stats
+wc -c $D/all.vcf.gz; rm -f $D/all.vcf.gz
+time $CLI filter $D/chr22 -o $D/all.vcf.gz --bgzf-level 1 --stats
+wc -c $D/all.vcf.gz; rm -f $D/all.vcf.gz
 echo "== filter keep-all, 1% samples"; time $CLI filter $D/chr22 --include-sam 'KEEP == "1"' -o $D/k.vcf --stats
 wc -c $D/k.vcf
