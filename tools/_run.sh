@@ -1,5 +1,5 @@
 set -o pipefail
-mkdir -p gpurun_out/r3o
-timeout -k 10 1000 python -m pytest tests/test_host_cli_gpu.py tests/test_host_cli_fullsize_gpu.py -x -q -m gpu > gpurun_out/r3o/tests.log 2>&1 || { tail -40 gpurun_out/r3o/tests.log; exit 1; }
-tail -3 gpurun_out/r3o/tests.log
-bash tools/e2e_chr22.sh > gpurun_out/r3o/e2e.log 2>&1; cat gpurun_out/r3o/e2e.log
+bash tools/profile_bench.sh r03_c3 > gpurun_out/r03_c3.txt 2>&1 || { tail -5 gpurun_out/r03_c3.txt; exit 1; }
+tail -4 gpurun_out/r03_c3.txt | cut -c1-300
+bash tools/profile_bench.sh r03_c5shard --config c5shard > gpurun_out/r03_c5shard.txt 2>&1 || { tail -5 gpurun_out/r03_c5shard.txt; exit 1; }
+tail -5 gpurun_out/r03_c5shard.txt | cut -c1-300
