@@ -322,8 +322,7 @@ static int dispatch_all_samples_lines(pgenhip_ctx *ctx, const EmitArgs &a)
         LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
     } else if (gt_pick_applicable(a)) {
         // shorter rows: the pick kernel (identity for a table) flushes each parked row behind its prefix
-        LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
-        LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+        LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));   // (writes the prefixes too)
     } else {
         LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
     }
@@ -519,12 +518,10 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
                 LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
             } else if (gt_pick_applicable(a)) {
                 // kept subset on short records: the pick kernel flushes each parked row behind its prefix
-                LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
-                LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));   // (writes the prefixes too)
             } else if (ctx->record_size >= 16u && !very_sparse(ctx)) {
                 // kept subset: the segment kernel writes each GT segment behind its prefix, the prefix kernel the rest
-                LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
-                LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
+                LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));   // (writes the prefixes too)
             } else {
                 LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
             }
@@ -539,7 +536,6 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
         case PGENHIP_KERNEL_SCAN:
             if (!ctx->subset || ctx->record_size < 16u) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_SCAN needs a kept-sample list and N >= 61");
             LAUNCH_TRY(launch_gt_scan(a, sc, t, ctx->num_cus, ctx->stream));
-            LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         case PGENHIP_KERNEL_RUNS:
             if (!gt_lineruns_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_RUNS (lines) needs dense records, >= 8 kept samples (of <= 4096 with a keep list) and two lines per item");
@@ -553,7 +549,6 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
         case PGENHIP_KERNEL_PICK:
             if (!gt_pick_applicable(a)) return fail(PGENHIP_ERR_BAD_ARG, "PGENHIP_KERNEL_PICK needs K >= 1 and 61 <= N <= 4096");
             LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));
-            LAUNCH_TRY(launch_copy_prefixes(a, ctx->num_cus, ctx->stream));
             return PGENHIP_OK;
         default:
             return fail(PGENHIP_ERR_BAD_ARG, "pgenhip_emit_lines supports kernel flags AUTO, ROWS, WIDE, SCAN, PICK, RUNS and ROWPICK");

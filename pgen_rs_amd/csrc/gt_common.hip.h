@@ -135,7 +135,7 @@ typedef uint32_t gt_v4u __attribute__((ext_vector_type(4)));
 
 // Byte 0 of row j's GT segment: out + j * out_stride, or — full-line mode (src/pfile.rs:156-192), any kept
 // subset — behind the line's prefix at out + line_off[j] + prefix length (the prefixes are copied by
-// copy_prefixes_kernel, gt_wide.hip).  j is wave-uniform or per-lane.
+// copy_prefix_rows below, run by the GT kernels' own waves).  j is wave-uniform or per-lane.
 __device__ __forceinline__ uint8_t *row_text(const EmitArgs &a, uint64_t j)
 {
     if (a.line_off != nullptr) return a.out + a.line_off[j] + (a.prefix_off[j + 1ull] - a.prefix_off[j]);
@@ -187,5 +187,57 @@ __device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8
     }
 }
 
+// ---- full-line mode: the lines' prefix bytes (pvar fields + "GT", src/pfile.rs:157-161) -------------------------------------
+// from the blob to out + line_off[j]: 1-2 % of the output bytes with plink2-made .pvar files, more with 1000 Genomes INFO columns
+// (130-250 bytes per line), byte granular at both ends because the neighbouring GT bytes belong to other waves.  The share of wave
+// `wave` of `n_waves`: 64 consecutive lines per round — their offsets with ONE coalesced load each (no dependent load chain per
+// line) — then eight or four lines per pass (8 / 16 lanes each, by the longest prefix: `shift`): whole destination-aligned dwords
+// (the four source bytes gathered), the up to three bytes before and behind them as bytes.
+// Round 2 ran this as a kernel of its own behind every GT kernel; at the CLI's launch granularity (13 000 lines per launch) that
+// cost 10-17 us beside a GT kernel of 43-52, for 0.4 % of the bytes (profiles/r02_cli_kernels.md).  Round 3: the GT kernels' own
+// waves do their share before their first work item (stream kernel: the STORER waves, while the loader's first record loads are in
+// flight and they would only wait).  Disjoint bytes, any order.
+__device__ __forceinline__ void copy_prefix_rows(const EmitArgs &a, uint32_t shift, uint64_t wave, uint64_t n_waves, uint32_t lane)
+{
+    const uint32_t group = lane >> shift, sub = lane & ((1u << shift) - 1u), per_pass = 64u >> shift, lanes = 1u << shift;
+    const uint64_t V = a.n_variants;
+    // lines per round: 64 on big launches; on small ones (the CLI's 13 000 lines over 7 000 waves) one pass' worth per wave, so that
+    // the copy is one offset load + one pass deep on many waves instead of eight dependent passes deep on a few
+    const uint64_t share = (V + n_waves - 1ull) / n_waves;
+    const uint32_t rpr = (uint32_t)min(64ull, max((uint64_t)per_pass, (share + per_pass - 1ull) / per_pass * per_pass));
+    for (uint64_t base = wave * rpr; base < V; base += n_waves * rpr) {
+        const uint64_t j = min(base + (uint64_t)min(lane, rpr - 1u), V - 1ull);
+        const uint64_t p0_l = a.prefix_off[j];
+        const uint32_t len_l = (uint32_t)(a.prefix_off[j + 1ull] - p0_l);
+        const uint64_t lo_l = a.line_off[j];
+        const uint32_t count = (uint32_t)min((uint64_t)rpr, V - base);
+        for (uint32_t i = 0; i < count; i += per_pass) {
+            const uint32_t li = min(i + group, count - 1u);      // (a short last pass: the spare groups repeat the last line, same bytes)
+            const uint64_t p0 = (uint64_t)__shfl((unsigned long long)p0_l, (int)li, 64);
+            const uint32_t len = (uint32_t)__shfl((int)len_l, (int)li, 64);
+            const uint64_t lo = (uint64_t)__shfl((unsigned long long)lo_l, (int)li, 64);
+            const uint8_t *__restrict__ src = a.prefix_blob + p0;
+            uint8_t *__restrict__ dst = a.out + lo;
+            const uint32_t head = min((uint32_t)(-(int32_t)(uint32_t)(uintptr_t)dst) & 3u, len);   // bytes before the first aligned dword
+            const uint32_t nd = (len - head) >> 2, tail = (len - head) & 3u;
+            for (uint32_t d = sub; d < nd; d += lanes) {
+                uint32_t w;
+                __builtin_memcpy(&w, src + head + 4u * d, 4);
+                *reinterpret_cast<uint32_t *>(dst + head + 4u * d) = w;
+            }
+            if (sub < head) dst[sub] = src[sub];
+            if (sub >= 4u && sub - 4u < tail) dst[head + 4u * nd + (sub - 4u)] = src[head + 4u * nd + (sub - 4u)];
+        }
+    }
+}
+
+
+// lanes per line of copy_prefix_rows as log2, by the launch's longest prefix (ms for 1 M lines of 2 504 samples with 30 / 100 / 166-byte
+// prefixes: 8 lanes 0.055 / 0.123 / 0.217, 16 lanes 0.076 / 0.117 / 0.162, 32 lanes - / 0.136 / 0.171); 0 = the launch has no prefix bytes
+__host__ __device__ inline uint32_t prefix_copy_shift(const EmitArgs &a)
+{
+    if (a.line_off == nullptr || a.prefix_blob == nullptr) return 0u;
+    return a.max_line_bytes - (4ull * a.kept_count + 1ull) <= 48ull ? 3u : 4u;
+}
 
 }  // namespace pgenhip

@@ -46,6 +46,7 @@ struct PickParams {
     uint32_t row_bytes;   // S = 4K + 1
     uint32_t magic;       // floor(2^32 / S) + 1: o / S = umulhi(o, magic) for o < 2^20 (checked on the host), fixed up by one compare
     uint32_t n_batches;
+    uint32_t pfx_shift;   // full lines: lanes per line (log2) of the in-kernel prefix copy, 0 = none
     uint32_t packed;      // 1: dense records, no gather — a batch's B records are ONE contiguous run of B*R bytes, fetched KiB by KiB and
                           // parked as they lie (pitch = R): short records no longer cost a load instruction and a register quad per
                           // ROW, and a batch is up to 64 rows instead of 12 (N = 300 with 30 samples kept: 7.7 KB of text per batch, not 1.4)
@@ -137,6 +138,8 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
 
     const uint32_t batch_step = gridDim.x * kWaves;
     uint32_t bi = blockIdx.x * kWaves + wave;
+    // full lines: this wave's share of the prefix bytes first (gt_common.hip.h)
+    if (LINES && p.pfx_shift != 0u) copy_prefix_rows(a, p.pfx_shift, (uint64_t)bi, (uint64_t)batch_step, lane);
     if (bi >= p.n_batches) return;
 
     v4u buf[kMaxBatchRows];
@@ -352,6 +355,7 @@ hipError_t launch_gt_pick(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     p.pieces = (a.record_size + 15u) / 16u;
     p.pitch = p.pieces * 16u;
     p.row_bytes = 4u * a.kept_count + 1u;
+    p.pfx_shift = prefix_copy_shift(a);
     // rows per batch: ~32 KiB of text per batch (8 / 16 / 32 / 64 KiB at 50 % kept on the chr22 shape: 1.44 / 1.41 / 1.37 / 1.36 ms),
     // what the stage holds, what the register buffer holds
     const uint32_t batch_bytes = t.pick_batch_bytes > 0 ? (uint32_t)t.pick_batch_bytes : 32768u;

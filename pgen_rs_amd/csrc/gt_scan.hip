@@ -97,6 +97,11 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     const uint64_t j0 = band_lo + (uint64_t)group_in_band * kWaves + wave;
     const uint64_t rows = j0 < band_hi ? (band_hi - j0 + row_step - 1ull) / row_step : 0ull;
 
+    // full lines: this wave's share of the prefix bytes first (gt_common.hip.h; every block comes by here, whatever its segment holds)
+    if (a.line_off != nullptr) {
+        const uint32_t pfx_shift = prefix_copy_shift(a);
+        if (pfx_shift != 0u) copy_prefix_rows(a, pfx_shift, (uint64_t)blockIdx.x * kWaves + wave, (uint64_t)gridDim.x * kWaves, lane);
+    }
     if (seg_cnt == 0u) {
         // nothing of this segment is kept; the last segment still owes every row its '\n' (:190)
         if (last_seg)

@@ -46,6 +46,7 @@ struct WideParams {
     uint32_t run_rows;       // RUNS mode: rows per work item (B)
     uint32_t run_rec;        // RUNS mode: bytes per row in the slab (R)
     uint32_t magic;          // RUNS mode: floor(2^32 / S) + 1: o / S = umulhi(o, magic), fixed up by one compare (o < 2^14)
+    uint32_t pfx_shift;      // LINES through the stream kernel: log2 of the lanes per line of the in-kernel prefix copy (0 = no prefixes to copy)
 };
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -689,6 +690,8 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_stream_dyn_kernel(EmitArgs a
     } else {
         // ------------------------------ storer waves -----------------------------
         const uint32_t w = wave - 1u;
+        // LINES: this wave's share of the lines' prefix bytes first (bytes no item writes; the loader's first loads are in flight meanwhile)
+        if (LINES && p.pfx_shift != 0u) copy_prefix_rows(a, p.pfx_shift, (uint64_t)blockIdx.x * NS + w, (uint64_t)gridDim.x * NS, lane);
         for (uint32_t step = 0;; step++) {  // 32-bit: a block that ran 2^32 steps would have written > 2^47 bytes
             const uint32_t slot = step % RS;
             while (lds_flag_read(lds_offset(&s_full[w][slot])) != step + 1u) __builtin_amdgcn_s_sleep(1);
@@ -1086,48 +1089,6 @@ __global__ __launch_bounds__(64 * (NS + 1)) void gt_lineruns_kernel(EmitArgs a, 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// copy_prefixes_kernel — LINES mode: line j's prefix bytes (pvar fields + "GT", src/pfile.rs:157-161)
-// from the blob to out + line_off[j].  1-2 % of the output bytes with plink2-made .pvar files, 1.6 % + with 1000 Genomes INFO
-// columns (130-250 bytes per line), byte granular at both ends because the neighbouring GT bytes belong to other waves.
-// A wave takes 64 consecutive lines per round: their offsets with ONE coalesced load each (no dependent load chain per line),
-// then eight or four lines per pass (8 / 16 lanes each, by the longest prefix): whole destination-aligned dwords (the four source bytes gathered), the up to three
-// bytes before and behind them as bytes.  (The first version — a quarter wave per line, three dependent offset loads and a byte
-// loop — took 0.20 ms beside the stream kernel's 1.89 ms on 1 M lines of 2 504 samples with 166-byte prefixes.)
-// `shift`: log2 of the lanes per line (3: eight lanes for prefixes up to 48 bytes, else 4: sixteen)
-__global__ __launch_bounds__(256) void copy_prefixes_kernel(EmitArgs a, uint32_t shift)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t group = lane >> shift, sub = lane & ((1u << shift) - 1u), per_pass = 64u >> shift, lanes = 1u << shift;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t V = a.n_variants;
-    for (uint64_t base = wave * 64ull; base < V; base += n_waves * 64ull) {
-        const uint64_t j = min(base + (uint64_t)lane, V - 1ull);
-        const uint64_t p0_l = a.prefix_off[j];
-        const uint32_t len_l = (uint32_t)(a.prefix_off[j + 1ull] - p0_l);
-        const uint64_t lo_l = a.line_off[j];
-        const uint32_t count = (uint32_t)min(64ull, V - base);
-        for (uint32_t i = 0; i < count; i += per_pass) {
-            const uint32_t li = min(i + group, count - 1u);      // (a short last pass: the spare groups repeat the last line, same bytes)
-            const uint64_t p0 = (uint64_t)__shfl((unsigned long long)p0_l, (int)li, 64);
-            const uint32_t len = (uint32_t)__shfl((int)len_l, (int)li, 64);
-            const uint64_t lo = (uint64_t)__shfl((unsigned long long)lo_l, (int)li, 64);
-            const uint8_t *__restrict__ src = a.prefix_blob + p0;
-            uint8_t *__restrict__ dst = a.out + lo;
-            const uint32_t head = min((uint32_t)(-(int32_t)(uint32_t)(uintptr_t)dst) & 3u, len);   // bytes before the first aligned dword
-            const uint32_t nd = (len - head) >> 2, tail = (len - head) & 3u;
-            for (uint32_t d = sub; d < nd; d += lanes) {
-                uint32_t w;
-                __builtin_memcpy(&w, src + head + 4u * d, 4);
-                *reinterpret_cast<uint32_t *>(dst + head + 4u * d) = w;
-            }
-            if (sub < head) dst[sub] = src[sub];
-            if (sub >= 4u && sub - 4u < tail) dst[head + 4u * nd + (sub - 4u)] = src[head + 4u * nd + (sub - 4u)];
-        }
-    }
-}
-
 }  // namespace
 
 bool gt_wide_applicable(const EmitArgs &a)
@@ -1135,19 +1096,6 @@ bool gt_wide_applicable(const EmitArgs &a)
     // rows of >= 4 KiB keep a wave's span reasonably full; R >= 16 for the clamped window reads
     return a.kept_idx == nullptr && a.line_off == nullptr && a.sample_count >= 1024u &&
            (a.n_variants <= 1 || a.out_stride == 4ull * a.kept_count + 1ull);
-}
-
-hipError_t launch_copy_prefixes(const EmitArgs &a, int num_cus, hipStream_t stream)
-{
-    if (a.n_variants == 0 || a.line_off == nullptr || a.prefix_blob == nullptr) return hipGetLastError();
-    const uint64_t blocks_needed = ((uint64_t)a.n_variants + 255ull) / 256ull;   // a wave takes 64 lines per round, four waves per block
-    const uint64_t pcap = (uint64_t)num_cus * 8ull;
-    const uint64_t max_prefix = a.max_line_bytes - (4ull * a.kept_count + 1ull);
-    // lanes per line, ms for 1 M lines of 2 504 samples with 30 / 100 / 166-byte prefixes: 8 lanes 0.055 / 0.123 / 0.217, 16 lanes 0.076 /
-    // 0.117 / 0.162, 32 lanes - / 0.136 / 0.171, the wave - / - / 0.251 (the quarter-wave byte loop of the first version: 0.087 / - / 0.202)
-    const uint32_t shift = max_prefix <= 48ull ? 3u : 4u;
-    hipLaunchKernelGGL(copy_prefixes_kernel, dim3((uint32_t)(blocks_needed < pcap ? blocks_needed : pcap)), dim3(256), 0, stream, a, shift);
-    return hipGetLastError();
 }
 
 bool gt_wide_lines_applicable(const EmitArgs &a)
@@ -1169,6 +1117,7 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     p.run_rows = 0u;
     p.run_rec = 0u;
     p.magic = 0u;
+    p.pfx_shift = 0u;
     // a row owns floor(S/16) or ceil(S/16) chunks (one more for row 0 with an unaligned pointer), and
     // its first span starts up to 63 chunks before them (1-KiB-aligned span grid)
     const uint64_t max_row_chunks = (p.row_bytes + 15ull) / 16ull + 1ull + 63ull;
@@ -1197,8 +1146,9 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
     const uint32_t g = (uint32_t)(need < cap ? need : cap);
     p.n_ranges = t.wide_ranges > 0 ? (uint32_t)t.wide_ranges : (p.spans_per_row > 1u && need >= 64ull * g ? 8u : 2u);
+    // LINES: the storer waves copy the prefixes themselves before their first item (lanes per line by the longest prefix: prefix_copy_shift)
+    p.pfx_shift = prefix_copy_shift(a);
     hipLaunchKernelGGL(dk, dim3(g), dim3(512), 0, stream, a, p);
-    if (a.line_off) return launch_copy_prefixes(a, num_cus, stream);  // the prefixes: disjoint bytes, same stream, any order
     return hipGetLastError();
 }
 
@@ -1240,6 +1190,7 @@ hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     p.run_rows = t.runs_rows > 0 && (uint32_t)t.runs_rows < run_rows_for(a) ? (uint32_t)t.runs_rows : run_rows_for(a);
     p.run_rec = a.record_size;
     p.magic = (uint32_t)(0x100000000ull / p.row_bytes) + 1u;
+    p.pfx_shift = 0u;
     p.n_items = ((uint64_t)a.n_variants + p.run_rows - 1ull) / p.run_rows;
     const uint64_t need = (p.n_items + 6ull) / 7ull;
     void (*dk)(EmitArgs, WideParams) = gt_stream_dyn_kernel<7, false, true, false, 2, true>;
@@ -1292,6 +1243,7 @@ hipError_t launch_gt_lineruns(const EmitArgs &a, const Tuning &t, int num_cus, h
     p.run_rows = t.runs_rows > 0 && (uint32_t)t.runs_rows < b_max ? (uint32_t)t.runs_rows : b_max;
     p.run_rec = a.record_size;
     p.magic = 0u;
+    p.pfx_shift = 0u;
     p.n_items = ((uint64_t)a.n_variants + p.run_rows - 1ull) / p.run_rows;
     // THREE storer waves per loader wave, not the stream kernel's seven: this loader has two dependent round trips and about as many
     // instructions per item as a storer has per 4-KiB group, so with seven storers it is the wave everybody waits for; and its

@@ -63,7 +63,6 @@ hipError_t launch_gt_flat(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
 // Same contract as the flat kernel, but records are staged with wide (16 B/lane) loads through LDS by a loader
 // wave and storer waves issue 16 coalesced 1-KiB stores per work item (rows >= 4 KiB of text; needs work_counters).
 bool gt_wide_applicable(const EmitArgs &a);
-hipError_t launch_copy_prefixes(const EmitArgs &a, int num_cus, hipStream_t stream);  // full-line mode: prefix bytes of every line
 bool gt_wide_lines_applicable(const EmitArgs &a);  // full-line mode (line_off/prefix_off set) through the stream kernel
 hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipStream_t stream);
 // RUNS mode of the same kernel for SHORT rows (8 <= N <= ~2000, dense records and dense text, no gather): a work item
