@@ -790,6 +790,13 @@ __device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WidePara
     const uint32_t pr_v = prel[min(lane, 31u)];
     auto line_start = [&](uint32_t l) { return (int32_t)__builtin_amdgcn_readlane(lr_v, (int)l); };                     // l <= nrows
     auto line_plen = [&](uint32_t l) { return (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)pr_v, (int)(l + 1u)) - (uint32_t)__builtin_amdgcn_readlane((int)pr_v, (int)l)); };
+    const float inv_mean = (float)nrows / (float)max(run_len, 1);   // lines per byte of the run (phase A's first guess of a chunk's line)
+    // phase B packs several seams into one wave pass when the launch's longest prefix (+ the '\n' in front of it) is short: 16 / 32 / 64 lanes per seam
+    const uint32_t seam_bytes = (uint32_t)(a.max_line_bytes - (uint64_t)(4u * a.kept_count + 1u)) + 1u;
+    const uint32_t seam_shift = seam_bytes <= 16u ? 4u : (seam_bytes <= 32u ? 5u : 6u);
+    // (only a prefix shorter than 15 bytes can leave a line's first GT bytes in a chunk that starts back in the previous line)
+    const uint32_t plen_v = (uint32_t)__shfl_down((int)pr_v, 1, 64) - pr_v;   // lane l: prefix length of line l (every lane takes part in the shuffle)
+    const bool short_prefix = __ballot(lane < nrows + (has_next ? 1u : 0u) && plen_v < 15u) != 0ull;
     for (uint32_t g = 0; g * 256u < end; g++) {
         const int32_t gb = c_first + 16 * ((int32_t)(g * 256u) - (int32_t)it.lead);        // run offset of stage byte 0
         const int32_t glo = max(gb, c_first), ghi = min(gb + 4096, own_end);               // the item's bytes in this group
@@ -798,44 +805,19 @@ __device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WidePara
         r_lo = (uint32_t)__popcll(__ballot(lane >= 1u && lr_v <= max(glo, 0)));            // (lanes > nrows hold INT_MAX)
         r_hi = (uint32_t)__popcll(__ballot(lane >= 1u && lr_v < ghi));
         // ---- A: every chunk that overlaps the GT text of the line its FIRST byte lies in, as 16 bytes of that line's text at the
-        // chunk's phase (bytes of the chunk outside the GT text are filler: phase B overwrites them)
-        // the group's lines, wave-uniform: start and first GT byte of lines r_lo .. r_lo + 11 (more lines per group only for N < 85)
-        constexpr uint32_t kGroupLines = 12;
-        const uint32_t n_more = min(r_hi, nrows) - min(r_lo, nrows);   // lines after r_lo that start inside the group
-        int32_t l_start[kGroupLines], l_gt[kGroupLines];                // scalars (readfirstlane): a compare against one costs one VALU
-#pragma unroll
-        for (uint32_t q = 0; q < kGroupLines; q++) {
-            l_start[q] = 0x7FFFFFFF;
-            l_gt[q] = 0;
-            if (q <= n_more) {  // wave-uniform
-                const uint32_t l = min(r_lo + q, nrows);
-                l_start[q] = line_start(l);
-                l_gt[q] = l_start[q] + line_plen(l);
-            }
-        }
-        const bool many_lines = r_hi - r_lo >= kGroupLines;
+        // chunk's phase (bytes of the chunk outside the GT text are filler: phase B overwrites them).
+        // Which line: the lines of a run differ only by their prefixes, so offset / (mean line length) is off by a line at most; two LDS
+        // reads of the run's line starts and a (rarely taken) walk settle it.  (Round 2 compared every chunk with up to 12 line starts
+        // held in scalars: 33 VALU per 64 chunks and 24 v_readlane per group — a quarter of this issue-bound kernel's instructions.)
 #pragma unroll
         for (uint32_t s4 = 0; s4 < 4u; s4++) {
             if (g * 256u + s4 * 64u >= end) break;
             const int32_t o = gb + 16 * (int32_t)(s4 * 64u + lane);
-            uint32_t rr = r_lo;
-            int32_t gt_lo = l_gt[0];
-#pragma unroll
-            for (uint32_t q = 1; q < kGroupLines; q++) {
-                if (q <= n_more && l_start[q] <= o) {  // (q <= n_more is wave-uniform: lines the group does not have cost a scalar branch)
-                    rr = r_lo + q;
-                    gt_lo = l_gt[q];
-                }
-            }
-            if (many_lines) {
-                for (uint32_t l = r_lo + kGroupLines; l <= r_hi && l <= nrows; l++) {
-                    const int32_t ls = (int32_t)lrel[l];
-                    if (ls <= o) {
-                        rr = l;
-                        gt_lo = ls + (int32_t)(prel[l + 1u] - prel[l]);
-                    }
-                }
-            }
+            uint32_t rr = min((uint32_t)((float)max(o, 0) * inv_mean), nrows);
+            int32_t ls = (int32_t)lrel[rr];
+            while (o < ls && rr > 0u) ls = (int32_t)lrel[--rr];
+            while (rr < nrows && o >= (int32_t)lrel[rr + 1u]) ls = (int32_t)lrel[++rr];
+            const int32_t gt_lo = ls + (int32_t)(prel[rr + 1u] - prel[rr]);   // (rr = nrows: not used below; prel has 32 entries, rr + 1 <= 31)
             const int32_t x = o - gt_lo;
             if (x > -16 && x < N4 && rr < nrows) {
                 const uint8_t *const rec = slab + delta + rr * R;
@@ -858,26 +840,40 @@ __device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WidePara
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- B: what lies between two lines' GT texts, byte by byte on top of A's chunks, one wave pass per line of the group
-        // (all bounds wave-uniform): line l-1's '\n', line l's prefix (lanes 0 .. plen), and — only when that prefix is so short that
-        // the chunk holding line l's first GT byte started back in line l-1 — line l's first GT bytes up to the chunk boundary
-        // (lanes 48 .. 62)
-        for (uint32_t l = r_lo; l <= min(r_hi + 1u, nrows); l++) {
-            const bool line_l = l < nrows || has_next;                        // line l's prefix (and first record byte) is in the slab
-            const int32_t ls = line_start(min(l, nrows));                      // start of line l (= run_len for l == nrows)
-            const int32_t plen = line_l ? line_plen(l) : 0;
-            const int32_t gt_lo = ls + plen;                                   // first GT byte of line l
-            const int32_t lim_hi = min(ghi, l == nrows && !has_next ? run_len : own_end);
-            for (int32_t b = (int32_t)lane; b <= plen; b += 64) {               // b = 0: the '\n' of line l-1, b = 1 .. plen: the prefix
-                const int32_t ob = ls - 1 + b;
-                if ((b >= 1 || l >= 1u) && ob >= glo && ob < lim_hi)
-                    stage[ob - gb] = b == 0 ? (uint8_t)'\n' : pfx[(uint32_t)__builtin_amdgcn_readlane((int)pr_v, (int)min(l, nrows)) + (uint32_t)(b - 1)];
+        // ---- B: what lies between two lines' GT texts, byte by byte on top of A's chunks: line l-1's '\n' and line l's prefix, lane <->
+        // byte, 1 / 2 / 4 seams per wave pass by the launch's longest prefix (round 2: one pass per seam, 45 instructions for ~31 bytes,
+        // 3.3 seams per group at N = 300 and 9.5 at N = 100)
+        const uint32_t l_hi = min(r_hi + 1u, nrows);
+        for (uint32_t l0 = r_lo; l0 <= l_hi; l0 += 64u >> seam_shift) {
+            const uint32_t l = l0 + (lane >> seam_shift);                       // this lane's line (one seam per pass: wave-uniform)
+            if (l <= l_hi) {
+                const uint32_t lc = min(l, nrows);
+                const bool line_l = l < nrows || has_next;                        // line l's prefix is in the slab
+                const int32_t ls = (int32_t)lrel[lc];                             // start of line l (= run_len for l == nrows)
+                const uint32_t pr = prel[lc];
+                const int32_t plen = line_l ? (int32_t)(prel[lc + 1u] - pr) : 0;
+                const int32_t lim_hi = min(ghi, l == nrows && !has_next ? run_len : own_end);
+                for (int32_t b = (int32_t)(lane & ((1u << seam_shift) - 1u)); b <= plen; b += (int32_t)(1u << seam_shift)) {   // b = 0: the '\n' of line l-1, b = 1 .. plen: the prefix
+                    const int32_t ob = ls - 1 + b;
+                    if ((b >= 1 || l >= 1u) && ob >= glo && ob < lim_hi) stage[ob - gb] = b == 0 ? (uint8_t)'\n' : pfx[pr + (uint32_t)(b - 1)];
+                }
             }
-            if (line_l && adown(gt_lo) < ls && lane >= 48u) {
-                const int32_t ob = gt_lo + (int32_t)(lane - 48u);
-                if (ob < aup(gt_lo) && ob >= glo && ob < lim_hi)
-                    stage[ob - gb] = (uint8_t)(PICK ? gt_text_byte(tab_code(slab + delta + l * R, tab, (int32_t)((lane - 48u) >> 2)), (lane - 48u) & 3u)
-                                                    : run_text_byte(slab, delta + l * R, lane - 48u));
+        }
+        // and — only when a prefix is so short that the chunk holding line l's first GT byte started back in line l-1 — line l's first GT
+        // bytes up to the chunk boundary (lanes 48 .. 62), one pass per such line
+        if (short_prefix) {
+            for (uint32_t l = r_lo; l <= l_hi; l++) {
+                const bool line_l = l < nrows || has_next;
+                const int32_t ls = line_start(min(l, nrows));
+                const int32_t plen = line_l ? line_plen(l) : 0;
+                const int32_t gt_lo = ls + plen;
+                const int32_t lim_hi = min(ghi, l == nrows && !has_next ? run_len : own_end);
+                if (line_l && adown(gt_lo) < ls && lane >= 48u) {
+                    const int32_t ob = gt_lo + (int32_t)(lane - 48u);
+                    if (ob < aup(gt_lo) && ob >= glo && ob < lim_hi)
+                        stage[ob - gb] = (uint8_t)(PICK ? gt_text_byte(tab_code(slab + delta + l * R, tab, (int32_t)((lane - 48u) >> 2)), (lane - 48u) & 3u)
+                                                        : run_text_byte(slab, delta + l * R, lane - 48u));
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
