@@ -791,9 +791,9 @@ __device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WidePara
     auto line_start = [&](uint32_t l) { return (int32_t)__builtin_amdgcn_readlane(lr_v, (int)l); };                     // l <= nrows
     auto line_plen = [&](uint32_t l) { return (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)pr_v, (int)(l + 1u)) - (uint32_t)__builtin_amdgcn_readlane((int)pr_v, (int)l)); };
     const float inv_mean = (float)nrows / (float)max(run_len, 1);   // lines per byte of the run (phase A's first guess of a chunk's line)
-    // phase B packs several seams into one wave pass when the launch's longest prefix (+ the '\n' in front of it) is short: 16 / 32 / 64 lanes per seam
+    // phase B: lanes per seam (log2) by the launch's longest prefix (+ the '\n' in front of it), four bytes per lane
     const uint32_t seam_bytes = (uint32_t)(a.max_line_bytes - (uint64_t)(4u * a.kept_count + 1u)) + 1u;
-    const uint32_t seam_shift = seam_bytes <= 16u ? 4u : (seam_bytes <= 32u ? 5u : 6u);
+    const uint32_t seam_shift = seam_bytes <= 16u ? 2u : (seam_bytes <= 32u ? 3u : (seam_bytes <= 64u ? 4u : (seam_bytes <= 128u ? 5u : 6u)));
     // (only a prefix shorter than 15 bytes can leave a line's first GT bytes in a chunk that starts back in the previous line)
     const uint32_t plen_v = (uint32_t)__shfl_down((int)pr_v, 1, 64) - pr_v;   // lane l: prefix length of line l (every lane takes part in the shuffle)
     const bool short_prefix = __ballot(lane < nrows + (has_next ? 1u : 0u) && plen_v < 15u) != 0ull;
@@ -840,12 +840,12 @@ __device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WidePara
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- B: what lies between two lines' GT texts, byte by byte on top of A's chunks: line l-1's '\n' and line l's prefix, lane <->
-        // byte, 1 / 2 / 4 seams per wave pass by the launch's longest prefix (round 2: one pass per seam, 45 instructions for ~31 bytes,
-        // 3.3 seams per group at N = 300 and 9.5 at N = 100)
+        // ---- B: what lies between two lines' GT texts, on top of A's chunks: line l-1's '\n' and line l's prefix.  A lane takes FOUR
+        // bytes of a seam and a seam takes 4 .. 64 lanes by the launch's longest prefix, so a wave pass covers up to 16 seams (round 2: one
+        // pass per seam, 45 instructions for ~31 bytes, 3.3 seams per 4-KiB group at N = 300 and 9.5 at N = 100)
         const uint32_t l_hi = min(r_hi + 1u, nrows);
         for (uint32_t l0 = r_lo; l0 <= l_hi; l0 += 64u >> seam_shift) {
-            const uint32_t l = l0 + (lane >> seam_shift);                       // this lane's line (one seam per pass: wave-uniform)
+            const uint32_t l = l0 + (lane >> seam_shift);                       // this lane's line (64 lanes per seam: wave-uniform)
             if (l <= l_hi) {
                 const uint32_t lc = min(l, nrows);
                 const bool line_l = l < nrows || has_next;                        // line l's prefix is in the slab
@@ -853,9 +853,13 @@ __device__ __forceinline__ void emit_lines_run(const EmitArgs &a, const WidePara
                 const uint32_t pr = prel[lc];
                 const int32_t plen = line_l ? (int32_t)(prel[lc + 1u] - pr) : 0;
                 const int32_t lim_hi = min(ghi, l == nrows && !has_next ? run_len : own_end);
-                for (int32_t b = (int32_t)(lane & ((1u << seam_shift) - 1u)); b <= plen; b += (int32_t)(1u << seam_shift)) {   // b = 0: the '\n' of line l-1, b = 1 .. plen: the prefix
-                    const int32_t ob = ls - 1 + b;
-                    if ((b >= 1 || l >= 1u) && ob >= glo && ob < lim_hi) stage[ob - gb] = b == 0 ? (uint8_t)'\n' : pfx[pr + (uint32_t)(b - 1)];
+                const int32_t lo_ok = l >= 1u ? 0 : 1;                           // (run line 0: the '\n' in front of it belongs to the run before)
+                for (int32_t b4 = 4 * (int32_t)(lane & ((1u << seam_shift) - 1u)); b4 <= plen; b4 += 4 << seam_shift) {
+#pragma unroll
+                    for (int32_t j = 0; j < 4; j++) {                             // b = 0: the '\n' of line l-1, b = 1 .. plen: the prefix
+                        const int32_t b = b4 + j, ob = ls - 1 + b;
+                        if (b <= plen && b >= lo_ok && ob >= glo && ob < lim_hi) stage[ob - gb] = b == 0 ? (uint8_t)'\n' : pfx[pr + (uint32_t)(b - 1)];
+                    }
                 }
             }
         }
