@@ -1,6 +1,8 @@
 set -o pipefail
-mkdir -p gpurun_out/r3s
-timeout -k 10 900 python -m pytest tests/test_gt_parity_gpu.py tests/test_host_cli_gpu.py -x -q -m gpu -k "lines or randomized or basic2 or tiny_keep" > gpurun_out/r3s/tests.log 2>&1 || { tail -30 gpurun_out/r3s/tests.log; exit 1; }
-tail -3 gpurun_out/r3s/tests.log
-for spec in "100 20000000 30" "300 8000000 30" "1000 2500000 30" "300 8000000 166" "100 20000000 10"; do set -- $spec; python tools/ab_probe.py --samples $1 --variants $2 --lines $3 --arms auto --rounds 5 2>&1 | tail -2; done > gpurun_out/r3s/ab.log; cat gpurun_out/r3s/ab.log
-python tools/ab_probe.py --samples 300 --variants 8000000 --lines 30 --keep-frac 0.5 --arms auto --rounds 5 2>&1 | tail -2 >> gpurun_out/r3s/ab.log; tail -2 gpurun_out/r3s/ab.log
+mkdir -p gpurun_out/r3t
+for n in 100 300 500 1000 1300; do for pfx in 30 166; do for keep in 0 0.5 0.1; do
+  v=$((2400000000 / (n * 4 + pfx + 300)))
+  extra=""; [ "$keep" != "0" ] && extra="--keep-frac $keep"
+  echo "## N=$n prefix=$pfx keep=$keep"; python tools/ab_probe.py --samples $n --variants $v --lines $pfx $extra --arms auto runs pick --rounds 3 2>&1 | grep -v amdgpu.ids | tail -4
+done; done; done > gpurun_out/r3t/lines_sweep.log 2>&1
+cat gpurun_out/r3t/lines_sweep.log
