@@ -56,6 +56,7 @@ KNOB_SCAN_TWO_PASS = 9
 KNOB_SCAN_CHUNK_ROWS = 10
 KNOB_ROWPICK_BLOCKS_PER_CU = 11
 KNOB_SCAN_ROWPICK = 12
+KNOB_PICK_LINE_SEAMS = 13
 
 
 

@@ -574,6 +574,7 @@ int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value)
         case PGENHIP_KNOB_SCAN_TWO_PASS: t.scan_two_pass = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_ROWPICK_BLOCKS_PER_CU: t.rowpick_blocks_per_cu = value > 0 ? value : d.rowpick_blocks_per_cu; break;
         case PGENHIP_KNOB_SCAN_ROWPICK: t.scan_rowpick = value < 0 ? 0 : (value == 2 ? 2 : 1); break;
+        case PGENHIP_KNOB_PICK_LINE_SEAMS: t.pick_line_seams = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_RUNS_ROWS: t.runs_rows = value > 0 ? value : d.runs_rows; break;
         default: return fail(PGENHIP_ERR_BAD_ARG, "unknown knob");
     }

@@ -336,6 +336,215 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// gt_pick_lines_kernel (round 3) — FULL LINES (pgenhip_emit_lines, src/pfile.rs:156-192) of short DENSE records, kept subset or
+// all samples: the CLI with `--include-sam` on the 1000 Genomes shape.
+//
+// Round 2 flushed every row of a batch on its own behind its prefix (whole chunks + one byte-store instruction for the row's two
+// ragged ends) and copied the prefixes separately.  SQ counters at N = 2 504 with 10 % kept (profiles/r03_kernel_sweeps.md): 94 VALU
+// per KiB of output against 145 in GT-segment mode — and still 0.44 of roofline against 0.60, 52 % of the wave cycles waiting: every
+// row left three separately written partial 128-B lines behind (its head, its tail, its prefix).
+//
+// Lines are packed back to back, so between the last WHOLE 16-byte chunk of row r's GT text and the first whole chunk of row r+1's
+// lies a SEAM that is itself a whole number of chunks: [last GT bytes of r | '\n' | prefix of r+1 | first GT bytes of r+1].  A batch
+// now writes (1) every row's interior as whole chunks (one pass of 64 lanes per KiB, the pick of gt_pick_kernel) and (2) all its
+// seams in a few wave passes, 4 .. 16 seams per pass by the launch's longest prefix, each lane building one chunk of one seam from
+// the two rows' texts and the prefix bytes (the batch's piece of the prefix blob is staged in LDS with the records).  Every byte
+// is written once, as part of a whole chunk; only the launch's first and last chunk can be ragged.
+// A batch owns the seams BEHIND its rows, so it stages one record more than it has rows (the row behind it), and the launch's first
+// batch also owns the piece in front of row 0.  Offsets are fetched two batches ahead (lane <-> row), so that the prefix bytes of
+// the next batch can be requested together with its records.
+constexpr uint32_t kPfxBytes = 2048;                         // prefix bytes of a batch (+ the row behind it) that the stage holds
+constexpr uint32_t kPfxStage = 16 + 16 + kPfxBytes + 16;     // 16 of slack in front, 15 of misalignment, 16 of slack behind
+
+struct PickLinesParams {
+    uint32_t batch_rows;   // B <= 62 (lanes 0 .. B + 1 hold the offsets of rows 0 .. B + 1 of the batch)
+    uint32_t n_batches;
+    uint32_t cps_shift;    // log2 of the lanes (= chunk slots) per seam: 2 .. 6
+};
+
+template <bool IDENT>
+__global__ __launch_bounds__(kThreads) void gt_pick_lines_kernel(EmitArgs a, PickLinesParams p)
+{
+    __shared__ uint16_t s_tab[kPadBefore + kMaxSamples + kPadAfter];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_pfx[kWaves][kPfxStage];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t K = a.kept_count;
+    if (!IDENT) {
+        for (uint32_t r = tid; r < kPadBefore + K + kPadAfter; r += (uint32_t)kThreads)
+            s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? (uint16_t)a.kept_idx[r - kPadBefore] : (uint16_t)0;
+    }
+    __syncthreads();
+    const uint16_t *const s_idx = s_tab + kPadBefore;
+    uint8_t *const stage = s_stage[wave];
+    uint8_t *const pstage = s_pfx[wave];
+    const uint32_t R = a.record_size, B = p.batch_rows;
+    const uint64_t V = a.n_variants;
+    const int32_t N4 = (int32_t)(4u * K);
+    const uint32_t step = gridDim.x * kWaves;
+    uint32_t bi = blockIdx.x * kWaves + wave;
+    if (bi >= p.n_batches) return;
+
+    // lane l: line and prefix offsets of row b * B + l (both arrays have V + 1 entries)
+    auto load_offs = [&](uint32_t b, uint64_t &lo, uint64_t &po) {
+        const uint64_t jr = min((uint64_t)b * B + (uint64_t)lane, V);
+        lo = a.line_off[jr];
+        po = a.prefix_off[jr];
+    };
+    auto lane64 = [&](uint64_t v, uint32_t l) {   // wave-uniform lane index
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+    };
+    // the records of rows b * B .. b * B + B (the row behind the batch comes along) as one byte run, from the 16-B boundary below it
+    v4u rbuf[kStageBytes / 1024];
+    auto load_records = [&](uint32_t b) {
+        const uint64_t row0 = (uint64_t)b * B;
+        const uint8_t *__restrict__ run0 = a.records + row0 * (uint64_t)R;
+        const uint32_t mis = (uint32_t)(uintptr_t)run0 & 15u;
+        const uint32_t n_bytes = mis + (uint32_t)min((uint64_t)B + 1ull, V - row0) * R;   // <= kStageBytes (host)
+#pragma unroll
+        for (uint32_t i = 0; i < kStageBytes / 1024u; i++) {
+            rbuf[i] = v4u{0u, 0u, 0u, 0u};
+            const uint32_t off = i * 1024u + lane * 16u;
+            if (i * 1024u < n_bytes && off < n_bytes) rbuf[i] = *reinterpret_cast<const v4u *>(run0 - mis + off);
+        }
+    };
+    // the prefixes of the same rows: blob bytes [po(row 0), po(row n)), from the 16-B boundary below them
+    v4u pbuf[2];
+    auto load_blob = [&](uint32_t b, uint64_t po) {
+        const uint32_t n = (uint32_t)min((uint64_t)B + 1ull, V - (uint64_t)b * B);
+        const uint64_t p0 = lane64(po, 0u), p1 = lane64(po, n);
+        const uint8_t *__restrict__ src = a.prefix_blob + p0;
+        const uint32_t mis = (uint32_t)(uintptr_t)src & 15u;
+        const uint32_t n_bytes = mis + (uint32_t)(p1 - p0);                                // <= 15 + kPfxBytes (host)
+#pragma unroll
+        for (uint32_t i = 0; i < 2u; i++) {
+            pbuf[i] = v4u{0u, 0u, 0u, 0u};
+            const uint32_t off = i * 1024u + lane * 16u;
+            if (p1 > p0 && off < n_bytes) pbuf[i] = *reinterpret_cast<const v4u *>(src - mis + off);
+        }
+    };
+
+    uint64_t lo0, po0, lo1 = 0ull, po1 = 0ull, lo2 = 0ull, po2 = 0ull;
+    load_offs(bi, lo0, po0);
+    if (bi + step < p.n_batches) load_offs(bi + step, lo1, po1);
+    load_records(bi);
+    load_blob(bi, po0);
+    for (;;) {
+        const uint64_t row0 = (uint64_t)bi * B;
+        const uint32_t rows_here = (uint32_t)min((uint64_t)B, V - row0);
+        // ---- park the records and the prefix bytes (waits for their loads and, one in-order vmcnt, for the previous batch's stores)
+        const uint32_t rmis = (uint32_t)(uintptr_t)(a.records + row0 * (uint64_t)R) & 15u;
+        {
+            const uint32_t n_bytes = rmis + (uint32_t)min((uint64_t)B + 1ull, V - row0) * R;
+#pragma unroll
+            for (uint32_t i = 0; i < kStageBytes / 1024u; i++)
+                if (i * 1024u < n_bytes) *reinterpret_cast<v4u *>(stage + i * 1024u + lane * 16u) = rbuf[i];
+        }
+        const uint64_t pbase = lane64(po0, 0u);
+        const uint32_t pmis = (uint32_t)(uintptr_t)(a.prefix_blob + pbase) & 15u;
+#pragma unroll
+        for (uint32_t i = 0; i < 2u; i++) *reinterpret_cast<v4u *>(pstage + 16u + i * 1024u + lane * 16u) = pbuf[i];
+        const uint8_t *const rows0 = stage + rmis;              // staged row i at rows0 + i * R
+        const uint8_t *const pfx0 = pstage + 16u + pmis;        // prefix byte t of the batch (relative to row 0's prefix start) at pfx0[t]
+        // ---- this batch's geometry, relative to its first line (32 bits: a batch is at most 63 lines)
+        const uint64_t lbase = lane64(lo0, 0u);
+        const uint32_t lrel = (uint32_t)(lo0 - lbase);          // lane l: start of line l
+        const uint32_t prel = (uint32_t)(po0 - pbase);          //         start of its prefix in the batch's prefix bytes
+        const uint32_t plen = (uint32_t)__shfl_down((int)prel, 1, 64) - prel;   // (every lane takes part in the shuffle)
+        const uint32_t grel = lrel + plen;                      //         first byte of its GT text
+        uint8_t *const out0 = a.out + lbase;
+        const uint32_t A0 = (uint32_t)(uintptr_t)out0 & 15u;
+        auto adown = [&](int32_t x) { return x - (int32_t)(((uint32_t)x + A0) & 15u); };
+        auto aup = [&](int32_t x) { return x + (int32_t)((0u - ((uint32_t)x + A0)) & 15u); };
+        // ---- the next batch's loads (its offsets arrived a batch ago), and the offsets of the batch after it
+        const uint32_t bi_next = bi + step;
+        const bool more = bi_next < p.n_batches;
+        if (more) {
+            load_records(bi_next);
+            load_blob(bi_next, po1);
+            if (bi_next + step < p.n_batches) load_offs(bi_next + step, lo2, po2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- (1) the rows' interiors: whole chunks inside [g, g + 4K)
+        for (uint32_t i = 0; i < rows_here; i++) {
+            const int32_t g = (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)grel, (int)i);
+            const int32_t q0 = aup(g) - g;                                       // 0 .. 15
+            const int32_t n_int = (N4 - q0) >> 4;
+            const uint8_t *row = rows0 + i * R;
+            for (int32_t c = (int32_t)lane; c < n_int; c += 64) {
+                const int32_t q = q0 + 16 * c;
+                const u32x4 v = pick_text16<IDENT>(row, s_idx, q, K);
+                *reinterpret_cast<v4u *>(out0 + g + q) = v4u{v.x, v.y, v.z, v.w};
+            }
+        }
+        // ---- (2) the seams behind rows 0 .. rows_here - 1 (and, first batch of the launch, the piece in front of row 0: seam -1)
+        const int32_t s_first = row0 == 0ull ? -1 : 0;
+        const uint32_t cps = 1u << p.cps_shift, spp = 64u >> p.cps_shift;
+        for (int32_t s_pass = s_first; s_pass < (int32_t)rows_here; s_pass += (int32_t)spp) {
+            const int32_t s = s_pass + (int32_t)(lane >> p.cps_shift);         // this lane's seam: between rows s and s + 1 of the batch
+            const uint32_t sl = (uint32_t)max(s, 0), sr = (uint32_t)(s + 1);
+            // (shuffles outside every branch: all lanes take part)
+            const int32_t g_l = (int32_t)__shfl((int)grel, (int)sl, 64);
+            const int32_t g_r = (int32_t)__shfl((int)grel, (int)sr, 64);
+            const int32_t l_r = (int32_t)__shfl((int)lrel, (int)sr, 64);
+            const int32_t p_r = (int32_t)__shfl((int)prel, (int)sr, 64);
+            const bool l_valid = s >= 0;
+            const bool r_valid = row0 + (uint64_t)sr < V;
+            const int32_t e_l = g_l + N4;                                        // row s's '\n'
+            const int32_t S0 = l_valid ? adown(e_l) : adown(l_r);
+            const int32_t S1 = r_valid ? aup(g_r) : aup(e_l + 1);
+            const int32_t V0 = l_valid ? S0 : l_r, V1 = r_valid ? S1 : e_l + 1;  // bytes of the seam that exist (ragged only at the launch's two ends)
+            const int32_t c0 = S0 + 16 * (int32_t)(lane & (cps - 1u));
+            if (s < (int32_t)rows_here && c0 < S1) {
+                const int32_t n1 = l_valid ? e_l - c0 : -1;                      // chunk bytes [0, n1): row s's text; byte n1: its '\n'
+                const int32_t n2 = r_valid ? g_r - c0 : 16;                      // chunk bytes (n1, n2): row s+1's prefix; [n2, 16): its text
+                u32x4 T = {0u, 0u, 0u, 0u}, H = {0u, 0u, 0u, 0u};
+                if (n1 > 0) T = pick_text16<IDENT>(rows0 + sl * R, s_idx, c0 - g_l, K);
+                if (n2 < 16) H = pick_text16<IDENT>(rows0 + sr * R, s_idx, c0 - g_r, K);
+                uint32_t P[4] = {0u, 0u, 0u, 0u};
+                if (r_valid && n2 > 0 && n1 < 15) {
+                    const uint8_t *pb = pfx0 + p_r + (c0 - l_r);                 // (>= 16 bytes of slack on both sides of the staged prefixes)
+#pragma unroll
+                    for (int t = 0; t < 16; t++) P[t >> 2] |= (uint32_t)pb[t] << (8 * (t & 3));
+                }
+                const uint32_t Ts[4] = {T.x, T.y, T.z, T.w}, Hs[4] = {H.x, H.y, H.z, H.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int32_t a1 = n1 - 4 * m, a2 = n2 - 4 * m;
+                    const uint32_t m1 = a1 >= 4 ? 0xFFFFFFFFu : (a1 <= 0 ? 0u : ((1u << (8 * a1)) - 1u));
+                    const uint32_t m2 = a2 >= 4 ? 0xFFFFFFFFu : (a2 <= 0 ? 0u : ((1u << (8 * a2)) - 1u));
+                    uint32_t d = (Ts[m] & m1) | (P[m] & ~m1 & m2) | (Hs[m] & ~m2);
+                    if (a1 >= 0 && a1 < 4) d = (d & ~(0xFFu << (8 * a1))) | (0x0Au << (8 * a1));   // (a1 < 0 for every m when there is no row s)
+                    o[m] = d;
+                }
+                uint8_t *const dst = out0 + c0;
+                if (c0 >= V0 && c0 + 16 <= V1) {
+                    *reinterpret_cast<v4u *>(dst) = v4u{o[0], o[1], o[2], o[3]};
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 16; t++)
+                        if (c0 + t >= V0 && c0 + t < V1) dst[t] = (uint8_t)(o[t >> 2] >> (8 * (t & 3)));
+                }
+            }
+        }
+        if (!more) break;
+        // the stages are rewritten by the next batch: this batch's reads must have returned first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bi = bi_next;
+        lo0 = lo1; po0 = po1;
+        lo1 = lo2; po1 = po2;
+    }
+}
+
 }  // namespace
 
 bool gt_pick_applicable(const EmitArgs &a)
@@ -380,6 +589,28 @@ hipError_t launch_gt_pick(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     p.batch_rows = b;
     p.magic = (uint32_t)(0x100000000ull / p.row_bytes) + 1u;    // exact up to one compare for run offsets < 2^20 (<= 12 rows of <= 16 385 bytes, or <= 64 rows within 32 KiB + one row)
     p.n_batches = (uint32_t)(((uint64_t)a.n_variants + b - 1u) / b);
+    // full lines of dense records: interiors + seams, every byte written once as part of a whole chunk (gt_pick_lines_kernel)
+    if (a.line_off != nullptr && p.packed && t.pick_line_seams != 0 && a.kept_count >= 4u && a.prefix_blob != nullptr) {
+        const uint64_t max_prefix = a.max_line_bytes - (uint64_t)p.row_bytes;
+        PickLinesParams lp;
+        uint32_t bl = b;
+        if (bl > 62u) bl = 62u;
+        if (15u + (bl + 1u) * a.record_size > kStageBytes) bl = (kStageBytes - 15u) / a.record_size - 1u;           // the row behind the batch comes along
+        if (max_prefix != 0ull && (uint64_t)(bl + 1u) * max_prefix > kPfxBytes - 16u) bl = (uint32_t)((kPfxBytes - 16u) / max_prefix) - 1u;   // and its prefix (two 1-KiB loads from the 16-B boundary below)
+        const uint32_t seam_chunks = (uint32_t)((max_prefix + 31ull) / 16ull);                                         // a seam is at most P + 31 bytes
+        lp.cps_shift = seam_chunks <= 4u ? 2u : (seam_chunks <= 8u ? 3u : (seam_chunks <= 16u ? 4u : (seam_chunks <= 32u ? 5u : 6u)));
+        if (max_prefix <= 993ull && (int32_t)bl >= 2 && bl <= 62u) {
+            lp.batch_rows = bl;
+            lp.n_batches = (uint32_t)(((uint64_t)a.n_variants + bl - 1u) / bl);
+            void (*lk)(EmitArgs, PickLinesParams) = a.kept_idx == nullptr ? gt_pick_lines_kernel<true> : gt_pick_lines_kernel<false>;
+            int lper_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&lper_cu, lk, kThreads, 0) != hipSuccess || lper_cu < 1) lper_cu = 1;
+            const uint64_t lneed = ((uint64_t)lp.n_batches + kWaves - 1ull) / kWaves;
+            const uint64_t lcap = (uint64_t)lper_cu * (uint64_t)num_cus;
+            hipLaunchKernelGGL(lk, dim3((uint32_t)(lneed < lcap ? lneed : lcap)), dim3(kThreads), 0, stream, a, lp);
+            return hipGetLastError();
+        }
+    }
     void (*kern)(EmitArgs, PickParams);
     if (a.kept_idx == nullptr) {
         if (a.line_off)

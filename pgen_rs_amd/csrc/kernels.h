@@ -39,6 +39,7 @@ struct Tuning {
     int wide_ranges = 0;           // stream kernel: work-queue ranges = write fronts of a launch (power of two <= 64); 0 = by shape (8 for rows of several spans, else 2)
     int flat_blocks_per_cu = 64;   // flat kernel: grid cap
     int scan_blocks_per_cu = 0;    // segment kernel: 0 = the measured rule (2 from ~0.6 % kept, else what the occupancy API says)
+    int pick_line_seams = 1;       // pick family, full lines of dense records: interiors + seams in one kernel (0 = round 2's row-by-row flush)
     int pick_batch_bytes = 32768;  // short-record pick kernel: text per batch (one store drain per batch)
     int scan_xcd_map = 1;          // segment kernels: all blocks of a row group on one XCD (seam lines merge in one L2); 0 = plain map
     int scan_chunk_rows = 0;       // two-pass path: rows per chunk (0 = as many as the 64-MiB compact scratch holds; tests force small chunks)
