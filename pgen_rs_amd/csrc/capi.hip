@@ -313,15 +313,15 @@ static int dispatch_all_samples_lines(pgenhip_ctx *ctx, const EmitArgs &a)
         // From N = 1 400: at N = 1 024 / 1 200 it runs at 0.45 / 0.49 of roofline against 0.48-0.51 for the two kernels below, at
         // N = 1 500 / 1 900 at 0.56 / 0.60 against 0.49-0.55 (profiles/r02_kernel_sweeps.md)
         LAUNCH_TRY(launch_gt_wide(a, t, ctx->num_cus, ctx->stream));
-    } else if (gt_lineruns_applicable(a) && (gt_lineruns_rows(a) >= 7u || a.sample_count >= 500u)) {
+    } else if (gt_lineruns_applicable(a) && gt_lineruns_rows(a) >= 7u && a.sample_count < 1000u) {
         // short rows, dense records: runs of whole lines (prefix + GT + '\n') assembled in LDS and stored as whole 128-B lines.
-        // Ahead of the row-by-row pick kernel below while a run holds seven lines or more (prefixes up to ~90 bytes): 0.30 / 0.43 of
-        // roofline at N = 100 / 300 with 30-byte prefixes against 0.24 / 0.38; with 166-byte prefixes a run is three lines and the
-        // pick kernel (packed batches, text offsets fetched per batch) is ahead below N = 500: 0.23 / 0.33 against 0.14 / 0.29
-        // (profiles/r02_kernel_sweeps.md)
+        // Ahead of the pick family's full-line kernel while a run holds seven lines or more (prefixes up to ~90 bytes) and N < 1 000:
+        // 30-byte prefixes, N = 100 / 300 / 500: 0.41 / 0.51 / 0.53 of roofline against 0.36 / 0.44 / 0.49; with 166-byte prefixes a run
+        // is three or four lines and the pick family is ahead at every N (0.37-0.52 against 0.14-0.50); from N = 1 000 it is level or
+        // ahead with short prefixes too (profiles/r03_logs/lines_sweep_after.log)
         LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
     } else if (gt_pick_applicable(a)) {
-        // shorter rows: the pick kernel (identity for a table) flushes each parked row behind its prefix
+        // the pick family (identity for a table): rows' interiors + batched seams (gt_pick_lines_kernel); gathered / padded records: row by row
         LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));   // (writes the prefixes too)
     } else {
         LAUNCH_TRY(launch_gt_rows(a, ctx->num_cus, ctx->stream));
@@ -510,14 +510,14 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
                 return PGENHIP_OK;
             }
             if (two_pass(ctx, a) && !very_sparse(ctx)) return dispatch_two_pass(ctx, a, sc);
-            if (gt_lineruns_applicable(a) && gt_lineruns_rows(a) >= 7u) {
-                // kept subset on SHORT dense records: runs of whole lines through the line-run kernel, picks through its LDS kept table.
-                // While a run holds seven lines or more (records of one wide load: N <= 520; prefixes of the slab's prefix area: up to
-                // ~90 bytes): 0.16-0.24 / 0.28-0.34 of roofline at N = 100 / 300 against 0.09-0.14 / 0.08-0.24 for the row-by-row pick
-                // kernel; with shorter runs the pick kernel is ahead (profiles/r02_kernel_sweeps.md)
+            if (gt_lineruns_applicable(a) && gt_lineruns_rows(a) >= 7u && a.sample_count < 300u) {
+                // kept subset on VERY short dense records: runs of whole lines through the line-run kernel, picks through its LDS kept table
+                // (N = 100, 30-byte prefixes, 50 / 10 % kept: 0.28 / 0.13 of roofline against 0.23 / 0.10 for the pick family's full-line
+                // kernel; from N = 300 that kernel is level or ahead — N = 500: 0.48 / 0.27 against 0.39 / 0.15 — and with long prefixes
+                // always: profiles/r03_logs/lines_sweep_after.log)
                 LAUNCH_TRY(launch_gt_lineruns(a, t, ctx->num_cus, ctx->stream));
             } else if (gt_pick_applicable(a)) {
-                // kept subset on short records: the pick kernel flushes each parked row behind its prefix
+                // kept subset on short records: the pick family (interiors + batched seams; gathered / padded records: row by row)
                 LAUNCH_TRY(launch_gt_pick(a, t, ctx->num_cus, ctx->stream));   // (writes the prefixes too)
             } else if (ctx->record_size >= 16u && !very_sparse(ctx)) {
                 // kept subset: the segment kernel writes each GT segment behind its prefix, the prefix kernel the rest

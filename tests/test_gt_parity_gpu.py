@@ -1008,8 +1008,9 @@ def test_wide_kernel_many_steps_ring_reuse(ranges):
 
 def _random_case(rng):
     """One random call of the path: shape, keep list, gather, strides, pointer phases, GT segments or full lines."""
-    # sample counts clustered around the dispatch thresholds of capi.hip (8, 400, 768, 1024, 1400, 1916, 4096, 65536) and spread between
-    edges = [1, 2, 7, 8, 9, 64, 399, 400, 401, 767, 768, 769, 1023, 1024, 1025, 1399, 1400, 1401, 1915, 1916, 1917, 2504, 4095, 4096, 4097, 20011, 65535, 65536, 65537]
+    # sample counts clustered around the dispatch thresholds of capi.hip (8, 61, 300, 400, 768, 1000, 1024, 1400, 1916, 4096, 65536) and spread between
+    edges = [1, 2, 7, 8, 9, 60, 61, 64, 299, 300, 301, 399, 400, 401, 767, 768, 769, 999, 1000, 1001, 1023, 1024, 1025, 1399, 1400, 1401, 1915, 1916, 1917, 2504, 4095, 4096, 4097, 20011,
+             65535, 65536, 65537]
     n = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 30_000))
     budget = int(rng.choice([300_000, 1_500_000, 6_000_000]))   # genotypes scanned per case: keeps the oracle in milliseconds
     v = int(min(max(1, budget // n), rng.choice([1, 2, 3, 17, 64, 257, 1031, 5003, 20011])))
