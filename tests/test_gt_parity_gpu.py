@@ -473,6 +473,70 @@ def test_row_owner_kernel_sparse_keeps_many_rows(n, k, v, mode):
                 assert got[3 : 3 + len(want)].tobytes() == want, f"kernel {kern}"
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_row_owner_kernel_randomized_forced(seed):
+    """The row-owner kernel FORCED (PGENHIP_KERNEL_ROWPICK) on random shapes AUTO would never give it: N from 61 to 200 000 (one to
+    thirteen segments, records that end anywhere in a tile), K from 1 to 16 384 in every arrangement (dense runs, empty segments,
+    first / last sample), few rows, gathered and padded records, padded output strides, unaligned pointers, GT segments and
+    full lines with prefixes of 0 .. 60 bytes; sentinels around everything it may not touch."""
+    rng = np.random.default_rng(4400 + seed)
+    for case_i in range(10):
+        n = int(rng.choice([61, 64, 300, 4096, 4097, 16384, 16385, 32768, 49153, 70001, 200_000])) if rng.random() < 0.7 else int(rng.integers(61, 120_000))
+        v = int(rng.choice([1, 2, 5, 33, 257]))
+        style = rng.choice(["sparse", "dense_run", "tiny", "ends", "modulus"])
+        if style == "sparse":
+            kept = np.sort(rng.choice(n, size=max(1, min(16384, int(n * rng.uniform(0.001, 0.05)))), replace=False))
+        elif style == "dense_run":
+            a0 = int(rng.integers(0, n - 1))
+            kept = np.arange(a0, min(n, a0 + int(rng.integers(1, min(16384, n) + 1))))
+        elif style == "tiny":
+            kept = np.sort(rng.choice(n, size=int(rng.integers(1, 4)), replace=False))
+        elif style == "ends":
+            kept = np.unique(np.array([0, n - 1, n // 2, min(n - 1, 16383), min(n - 1, 16384)]))
+        else:
+            kept = np.arange(int(rng.integers(0, 7)), n, int(rng.integers(max(2, n // 16000 + 1), 200)))[:16384]
+        kept = kept.astype(np.uint32)
+        k = int(kept.size)
+        r = oracle.variant_record_size(n)
+        gather = bool(rng.random() < 0.4)
+        rstride = r + (int(rng.choice([0, 1, 7, 16])) if gather else 0)
+        v_file = 2 * v if gather else v
+        rec_off = int(rng.integers(0, 17))
+        recs = rng.integers(0, 256, size=rec_off + v_file * rstride + 16, dtype=np.uint8)
+        vidx = rng.integers(0, v_file, size=v).astype(np.uint32) if gather else None
+        dense = np.concatenate([recs[rec_off + i * rstride : rec_off + i * rstride + r] for i in range(v_file)])
+        lines = bool(rng.random() < 0.5)
+        tag = f"seed={seed} case={case_i} n={n} v={v} k={k} style={style} gather={gather} rstride={rstride} lines={lines}"
+        with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+            rec_t = torch.from_numpy(recs).to(DEV)
+            vidx_t = None if vidx is None else torch.tensor(vidx.astype(np.int64), dtype=torch.int32, device=DEV)
+            out_off = int(rng.integers(0, 40))
+            if lines:
+                plens = rng.integers(0, 61, size=v)
+                prefixes = [bytes(rng.integers(33, 127, size=int(q), dtype=np.uint8)) for q in plens]
+                blob = np.frombuffer(b"".join(prefixes) + b"!", dtype=np.uint8)
+                poff = np.cumsum([0] + [len(q) for q in prefixes]).astype(np.int64)
+                loff = np.cumsum([0] + [len(q) + 4 * k + 1 for q in prefixes]).astype(np.int64)
+                want = oracle.emit_lines(dense, v, n, blob, poff.astype(np.uint64), loff.astype(np.uint64), kept_idx=kept, variant_idx=vidx)
+                out = torch.full((out_off + int(loff[-1]) + 32,), SENTINEL, dtype=torch.uint8, device=DEV)
+                eng.emit_lines(rec_t, v, torch.from_numpy(blob.copy()).to(DEV), torch.from_numpy(poff).to(DEV), torch.from_numpy(loff).to(DEV), 60, out[out_off:],
+                               record_stride=rstride, variant_idx=vidx_t, kernel=_capi.KERNEL_ROWPICK, records_offset=rec_off)
+                eng.wait()
+                got = out.cpu().numpy()
+                assert (got[:out_off] == SENTINEL).all() and (got[out_off + want.size :] == SENTINEL).all(), tag + ": wrote outside the lines"
+                assert got[out_off : out_off + want.size].tobytes() == want.tobytes(), tag
+            else:
+                ostride = 4 * k + 1 + int(rng.choice([0, 0, 3, 16]))
+                want = oracle.decode_emit(dense, v, n, kept_idx=kept, variant_idx=vidx).reshape(v, -1)
+                out = torch.full((out_off + v * ostride + 32,), SENTINEL, dtype=torch.uint8, device=DEV)
+                eng.decode_emit(rec_t, v, record_stride=rstride, variant_idx=vidx_t, out=out, out_stride=ostride, kernel=_capi.KERNEL_ROWPICK,
+                                out_offset=out_off, records_offset=rec_off)
+                eng.wait()
+                got = out.cpu().numpy()
+                exp = expect_buffer(want, v, k, ostride, out_off, got.size)
+                assert (got == exp).all(), tag
+
+
 @pytest.mark.parametrize("lines", [False, True])
 def test_two_pass_launches_of_one_ctx_on_different_streams_overlap(lines):
     """The same promise on the TWO-PASS path (sparse keeps on long records, BASELINE configs[4]'s band): pass 1 parks a
