@@ -193,12 +193,13 @@ int pgenhip_decode_emit_at(pgenhip_ctx *ctx, const void *d_base, const uint64_t 
  * then "GT", :157-161) + GT segment + '\n', written at d_out + d_line_off[j].
  * d_prefix_off/d_line_off are device arrays of n_variants+1 u64 with
  * d_line_off[j+1]-d_line_off[j] == prefix_len(j) + 4K + 1 (lines packed back to back);
- * max_prefix_bytes is a host-known upper bound of any prefix length (sizes the grid).
- * flags: PGENHIP_KERNEL_AUTO (all samples kept and sample_count >= 1024: the work-queue
- * stream kernel writes each GT segment in place behind its prefix and a small kernel copies
- * the prefixes; a kept subset on records of >= 16 bytes: the scan-family kernels write the GT
- * segments and the same small kernel the prefixes; otherwise the general kernel),
- * PGENHIP_KERNEL_ROWS, PGENHIP_KERNEL_WIDE, PGENHIP_KERNEL_SCAN, PGENHIP_KERNEL_PICK, PGENHIP_KERNEL_RUNS or PGENHIP_KERNEL_ROWPICK to force one (tests, A/B). */
+ * max_prefix_bytes is a host-known upper bound of any prefix length.  It must be a TRUE bound: the kernels size their LDS staging
+ * and their seam passes by it; with a smaller value lines come out wrong (nothing is read or written out of bounds).
+ * flags: PGENHIP_KERNEL_AUTO picks by shape — all samples kept: the work-queue stream kernel from 1 400 samples (GT segments
+ * in place behind their prefixes), below it runs of whole lines assembled in LDS (short prefixes, N < 1 000) or the pick
+ * family's interiors + seams kernel; a kept subset: the pick family on records of up to 4 096 samples, the segment kernels or
+ * the two passes on longer ones, the general kernel for tiny shapes.  Every kernel writes the prefixes itself (no separate
+ * copy).  PGENHIP_KERNEL_ROWS, _WIDE, _SCAN, _PICK, _RUNS or _ROWPICK force one (tests, A/B). */
 int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_stride,
                        const uint32_t *d_variant_idx, uint32_t n_variants,
                        const void *d_prefix_blob, const uint64_t *d_prefix_off,
