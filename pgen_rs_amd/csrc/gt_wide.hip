@@ -1142,11 +1142,12 @@ hipError_t launch_gt_wide(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     // block: 2 blocks/CU 2.12 ms, 4 blocks/CU 2.00 ms (profiles/r01_kernel_sweeps.md)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dk, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-    // ... on launches of more than ~5 GB of text.  Shorter launches run FASTER with two blocks per CU, at every row length
-    // (round 3, profiles/r03_kernel_sweeps.md §6; fraction of roofline at 2 / 4 blocks per CU): N = 2 504, 134 MB (a CLI block) 0.51 / 0.45,
-    // 2.2 GB 0.77 / 0.71, 4.5 GB 0.74 / 0.72, 6 GB 0.69 / 0.73; N = 10 000, 2.4 GB 0.78 / 0.74, 7.2 GB 0.73 / 0.74; N = 500 000, 4 GB 0.79 /
-    // 0.77, 16 GB 0.74 / 0.75; K = 4 940 (the second pass of the two passes, 0.5 GB) 0.72 / 0.66.
-    if ((uint64_t)a.n_variants * p.row_bytes <= 4500000000ull && per_cu > 2) per_cu = 2;
+    // ... on long launches.  SHORT launches (up to ~1 GB of text: a CLI block, a chunk of the two passes) run faster with two blocks per
+    // CU (round 3, profiles/r03_kernel_sweeps.md §6).  On a re-used output buffer (what the CLI does) the advantage is large and holds up to
+    // ~4.5 GB (N = 2 504: 134 MB 0.51 against 0.45 of roofline, 2.2 GB 0.77 / 0.71, 6 GB 0.69 / 0.73); on FRESH output regions (one call cut into
+    // pieces of that size, tools/split_probe.py) it is small and ends earlier: 134 MB 0.457 / 0.442, 0.5 GB level (K = 4 940: 0.584 / 0.569),
+    // 2 GB 0.613 / 0.642 — so the rule takes the size both agree on.
+    if ((uint64_t)a.n_variants * p.row_bytes <= 1000000000ull && per_cu > 2) per_cu = 2;
     if (t.wide_blocks_per_cu > 0) per_cu = t.wide_blocks_per_cu;
     const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
     const uint32_t g = (uint32_t)(need < cap ? need : cap);
@@ -1202,8 +1203,9 @@ hipError_t launch_gt_runs(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     // two blocks per CU, not the three the occupancy API allows (45 KB of LDS each): level on 11-GB launches (N = 100 / 300 / 1 000 /
     // 1 900: 0.686 / 0.680 / 0.698 / 0.707 against 0.683 / 0.681 / 0.703 / 0.690) and 8-9 % ahead on the 255-MB launch of the
     // reference's own dataset shape (0.505 against 0.469), whose blocks run only three steps each
-    // (round 3: from ~5.5 GB of text three are ahead again — 3.2 M rows of N = 300, 3.9 GB: 0.71 / 0.69 at 2 / 3 per CU; 6.4 M rows: 0.69 / 0.73)
-    int per_cu = p.total_bytes > 5500000000ull ? 3 : 2;
+    // (round 3: on one box three were ahead again from ~5.5 GB of re-used output — 6.4 M rows of N = 300: 0.73 against 0.69 — which round 2's
+    // boxes did not show; left at two)
+    int per_cu = 2;
     if (t.wide_blocks_per_cu > 0) per_cu = t.wide_blocks_per_cu;
     const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
     hipLaunchKernelGGL(dk, dim3((uint32_t)(need < cap ? need : cap)), dim3(512), 0, stream, a, p);
