@@ -23,7 +23,8 @@ One JSON line on stdout (rank 0).  Besides the contract's keys:
   `roofline`       HBM; algorithmic bytes (R + 4K + 1 per variant) / hipEvent time on the
                    kernel's stream; per-step event pairs give min / median / max (the output buffer's
                    physical placement moves a launch by 5-9 % between processes, DESIGN.md §4);
-                   `traffic` from the committed PMC passes of the same shape (profiles/r0*/pmc_summary.json, latest round first)
+                   `traffic` MEASURED IN THE RUN by two child passes under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE);
+                   if the profiler is not available: from the committed PMC passes of the same shape (profiles/r0*/pmc_summary.json)
   `cpu_baseline`   the oracle's literal restatement of the reference loop, 1 core, same N, bounded V
   `host_delivered` PCIe-inclusive rate (pinned host records -> H2D || kernel || D2H -> pinned host text),
                    measured OUTSIDE the timed region; it is never `value`
@@ -365,6 +366,54 @@ def secondary_one(torch, pgen_rs_amd, name: str, dev_index: int, steps: int, war
     return res
 
 
+def measure_traffic_live(argv_shape: list[str], timeout_s: int = 300):
+    """HBM bytes per pgenhip_decode_emit call of THIS workload, measured now: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the L2's memory-side counters do not fit one pass;
+    `--kernel-trace` only, as the pool requires with `--pmc`), summed over every GT kernel of a call.  Units KiB; FETCH_SIZE
+    doubled (gfx950 tallies the 128-B requests of 16-B-per-lane streaming loads at 64 B: MI355X_MICROARCH.md).  Children of this
+    process (it never execs itself), run after its own buffers are freed.  Returns (bytes per call, note) or raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if "ROCP_TOOL_LIBRARIES" in os.environ or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("already running under a profiler")
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(rocprof).exists():
+        raise RuntimeError("rocprofv3 not found")
+    per_call = {}
+    child_args = [sys.executable, str(Path(__file__).resolve()), *argv_shape, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-delivered",
+                  "--no-secondary", "--no-live-traffic"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"pgenhip_pmc_{counter.lower()}_", dir="/tmp")
+        try:
+            p = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", *child_args],
+                               capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                raise RuntimeError(f"child under rocprofv3 --pmc {counter} failed (rc {p.returncode}): {(p.stderr or p.stdout)[-300:]}")
+            child = json.loads(lines[-1])
+            calls = (child["steps"] + child["warmup"]) * child["config"]["launches_per_step"]
+            total = 0.0
+            for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and "pgenhip" in r["Kernel_Name"] and "synth" not in r["Kernel_Name"]:
+                        total += float(r["Counter_Value"])
+            if total <= 0.0 or calls <= 0:
+                raise RuntimeError(f"no {counter} samples for the GT kernels")
+            per_call[counter] = total / calls
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    hbm = int((2.0 * per_call["FETCH_SIZE"] + per_call["WRITE_SIZE"]) * 1024)
+    note = (f"measured in this run: two child passes of this workload under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (KiB per call: "
+            f"{per_call['FETCH_SIZE']:.0f} / {per_call['WRITE_SIZE']:.0f}; FETCH_SIZE doubled for 16-B/lane streaming loads per MI355X_MICROARCH.md), "
+            "summed over every GT kernel of one pgenhip_decode_emit call")
+    return hbm, note
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -381,6 +430,8 @@ def main() -> int:
     ap.add_argument("--max-launch-variants", type=int, default=0, help="cap on variants per launch (0 = as many as fit in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-delivered", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with child rocprofv3 --pmc passes; read it from the committed profile of the same shape")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (the other BASELINE shapes after the headline)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
@@ -519,7 +570,24 @@ def main() -> int:
         alg_bytes_per_step = v * (r + 4 * k + 1)
         launch_ms = event_ms_max / launches                    # max-over-ranks event time / launches per rank
         achieved_gbs = alg_bytes_per_step / (event_ms_max / args.steps * 1e-3) / 1e9
-        traffic, traffic_note = load_traffic(v_launch, n, k)
+        traffic, traffic_note = None, None
+        if world == 1 and not args.no_live_traffic:
+            # live: free this process's buffers first, the children need the same HBM
+            recs = out = None
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
+            shape_argv = ["--config", cfg_name, "--distribution", args.distribution]
+            if custom:
+                shape_argv += ["--variants", str(v_total), "--samples", str(n), "--keep-modulus", str(keep_mod)]
+            if args.max_launch_variants:
+                shape_argv += ["--max-launch-variants", str(args.max_launch_variants)]
+            try:
+                traffic, traffic_note = measure_traffic_live(shape_argv)
+            except Exception as e:  # noqa: BLE001 — the line must come out whatever the profiler does
+                traffic_note = f"live PMC passes not available ({type(e).__name__}: {str(e)[:200]}); "
+        if traffic is None:
+            t_file, note_file = load_traffic(v_launch, n, k)
+            traffic, traffic_note = t_file, (traffic_note or "") + (f"from the committed profile {note_file}" if note_file else "no committed profile of this shape")
         shape = f"{v_total} variants x {n} samples, " + ("all samples kept" if kept is None else f"{k} samples kept (splitmix64 mask, 1/{keep_mod})")
         if custom:
             workload = f"custom shape ({shape}); derived from preset {cfg_name}"
