@@ -219,7 +219,7 @@ typedef enum pgenhip_knob {
     PGENHIP_KNOB_SCAN_TWO_PASS = 9,      /* sparse keeps on long records: 1 (default) compact pass + all-samples pass, -1 single-pass segment kernel */
     PGENHIP_KNOB_SCAN_CHUNK_ROWS = 10,   /* two-pass path: rows per chunk (default: as many as the 64-MiB compact scratch holds) */
     PGENHIP_KNOB_ROWPICK_BLOCKS_PER_CU = 11, /* row-owner kernel: cap on resident blocks per CU (default: occupancy API) */
-    PGENHIP_KNOB_SCAN_ROWPICK = 12,      /* sparse keeps on long records, chunks of many rows: 1 (default) the row-owner kernel as the compact pass of the two passes, 2 the row-owner kernel writing text in ONE pass, -1 the segment kernel as the compact pass */
+    PGENHIP_KNOB_SCAN_ROWPICK = 12,      /* kept subsets on long records, launches of many rows: 1 (default) the row-owner kernel where it measures ahead (text in one pass for 2-20 % kept and for records of barely more than one segment; compact pass of the two passes below 2 %), 2 also in ONE pass across the two-pass band, -1 never (segment kernels) */
     PGENHIP_KNOB_PICK_LINE_SEAMS = 13,   /* short dense records, full lines: 1 (default) rows' interiors + batched seams (every byte written once in a whole chunk), -1 round 2's row-by-row flush */
     PGENHIP_KNOB_RUNS_ROWS = 7           /* RUNS kernel: rows per work item (default: as many as one wide load / one span holds) */
 } pgenhip_knob;

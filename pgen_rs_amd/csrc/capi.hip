@@ -271,14 +271,23 @@ static bool very_sparse(const pgenhip_ctx *ctx)
     return ctx->sample_count >= 65536u && (uint64_t)ctx->kept_count * 280ull <= ctx->sample_count;
 }
 
-// Sparse keeps on long records with many rows in the launch, ONE pass through the row-owner kernel (gt_rowpick.hip writing text):
-// opt-in (PGENHIP_KNOB_SCAN_ROWPICK = 2).  Measured on BASELINE configs[4]'s shard it is 3-6 % BEHIND the two passes (3.33-3.67 ms
-// against 3.27-3.40): a launch that reads 86 % and writes 14 % of its bytes everywhere at once runs at the copy ceiling (5.4 TB/s
-// of total traffic), while a pass that only reads followed by a pass that only writes run at 5.8 and 4.7 (profiles/r03_kernel_sweeps.md).
-// The default use of that kernel is as the COMPACT pass of the two passes (dispatch_two_pass).
+// Kept subsets on long records through the row-owner kernel WRITING TEXT (gt_rowpick.hip, one pass): the whole kept list fits its LDS
+// table (K <= 16 384) and the launch has enough rows for every resident wave.  Where it is ahead of the segment kernel / the two passes
+// (profiles/r03_kernel_sweeps.md §7, fraction of roofline against the previous dispatch):
+//   * records of one full segment and a thin second one (16 384 < N < 24 576): the segment kernel's blocks are unbalanced there —
+//     N = 16 385 with 10 / 50 % kept 0.57 / 0.55 against 0.39 / 0.38, N = 20 000 with 10 / 30 / 80 % 0.60 / 0.57 / 0.51 against 0.50 / 0.43 / 0.43;
+//   * 2 % .. 20 % kept on longer records: N = 30 000 5 % 0.62 / 0.53, N = 60 000 10 % 0.60 / 0.58, N = 100 000 2 / 5 % 0.65 / 0.62 against 0.62 / 0.56,
+//     N = 500 000 3.2 % 0.62 / 0.58 (level from ~20 %: N = 60 000 25 % 0.565 / 0.571; behind at 50 %).
+// Below 2 % the two passes keep the sparse band (BASELINE configs[4], 1 % of 500 000: one pass reads 86 % and writes 14 % of its bytes
+// everywhere at once and runs at the copy ceiling, 3-6 % behind; N = 200 000 1 %: 0.635 against 0.658).
+// PGENHIP_KNOB_SCAN_ROWPICK = 2 takes the one pass wherever it is applicable in the two-pass band too (A/B), -1 nowhere.
 static bool rowpick_shape(const pgenhip_ctx *ctx, const EmitArgs &a)
 {
-    return ctx->tune.scan_rowpick == 2 && two_pass_shape(ctx->sample_count, ctx->kept_count) && !very_sparse(ctx) && gt_rowpick_applicable(a, ctx->num_cus);
+    if (ctx->tune.scan_rowpick == 0 || ctx->sample_count <= kScanSegmentSamples || very_sparse(ctx) || !gt_rowpick_applicable(a, ctx->num_cus)) return false;
+    const uint64_t N = ctx->sample_count, K = ctx->kept_count;
+    if (ctx->tune.scan_rowpick == 2 && two_pass_shape(ctx->sample_count, ctx->kept_count)) return true;
+    if (N < 24576ull) return true;
+    return K * 50ull >= N && K * 5ull <= N;
 }
 
 // AUTO for all samples kept, GT segments at a.out + j * a.out_stride
@@ -505,7 +514,10 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;
             if (a.kept_idx == nullptr) return dispatch_all_samples_lines(ctx, a);
-            if (rowpick_shape(ctx, a)) {
+            // (full lines: only on records of barely more than one segment, or on request — the row-owner kernel fetches a row's prefix when it
+            // emits the row, a dependent load per row: N = 60 000 with 10 % kept 0.59 of roofline against the segment kernel's 0.67, while
+            // N = 20 000 with 30 % is 0.58 against 0.46)
+            if (rowpick_shape(ctx, a) && (ctx->sample_count < 24576u || ctx->tune.scan_rowpick == 2)) {
                 LAUNCH_TRY(launch_gt_rowpick(a, sc, t, ctx->num_cus, ctx->stream));   // (writes the prefixes too)
                 return PGENHIP_OK;
             }

@@ -230,8 +230,10 @@ bool plan(const EmitArgs &a, const Tuning &t, int num_cus, bool compact, RowPick
     else L.kern = gathered(a) ? gt_rowpick_kernel<true, false> : gt_rowpick_kernel<false, false>;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L.kern, kThreads, L.lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    // two blocks per CU measure best (the loads of 8 waves per CU already saturate the read path: tools/readbench.hip; 3: level, 5: -3 %)
-    const int want = t.rowpick_blocks_per_cu > 0 ? t.rowpick_blocks_per_cu : 2;
+    // two blocks per CU measure best on long records (the loads of 8 waves per CU already saturate the read path: tools/readbench.hip; 3:
+    // level, 5: -3 %); on records of barely more than one segment, where a row is mostly text to write, all that fit (N = 16 385 with
+    // 10 % kept: 0.51 / 0.57 / 0.56 of roofline at 2 / 3 / 4 per CU; N = 20 000 with 30 %: 0.52 / 0.56 / 0.57)
+    const int want = t.rowpick_blocks_per_cu > 0 ? t.rowpick_blocks_per_cu : (!compact && a.sample_count < 24576u ? 4 : 2);
     if (want < per_cu) per_cu = want;
     L.max_blocks = (uint32_t)per_cu * (uint32_t)num_cus;
     return true;
