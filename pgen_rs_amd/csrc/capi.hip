@@ -514,10 +514,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;
             if (a.kept_idx == nullptr) return dispatch_all_samples_lines(ctx, a);
-            // (full lines: only on records of barely more than one segment, or on request — the row-owner kernel fetches a row's prefix when it
-            // emits the row, a dependent load per row: N = 60 000 with 10 % kept 0.59 of roofline against the segment kernel's 0.67, while
-            // N = 20 000 with 30 % is 0.58 against 0.46)
-            if (rowpick_shape(ctx, a) && (ctx->sample_count < 24576u || ctx->tune.scan_rowpick == 2)) {
+            if (rowpick_shape(ctx, a)) {
                 LAUNCH_TRY(launch_gt_rowpick(a, sc, t, ctx->num_cus, ctx->stream));   // (writes the prefixes too)
                 return PGENHIP_OK;
             }

@@ -34,6 +34,11 @@ constexpr uint32_t kStageBytes = kSegSamples / 4u;
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ uint64_t sgpr64_(uint64_t v)   // a wave-uniform value into scalar registers (readfirstlane returns int: widen through uint32_t)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
 // bytes of dynamic LDS: table (K + 8 u16, 16-B rounded) | kept-before-segment (n_seg + 1 u32, 16-B rounded) | per wave: stage + compact record
 __host__ __device__ inline uint32_t table_bytes(uint32_t K) { return (2u * (K + 8u) + 15u) & ~15u; }
 __host__ __device__ inline uint32_t rank_bytes(uint32_t n_seg) { return (4u * (n_seg + 1u) + 15u) & ~15u; }
@@ -127,6 +132,26 @@ __global__ __launch_bounds__(kThreads) void gt_rowpick_kernel(EmitArgs a, ScanAr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
+    // full lines: offsets and prefix bytes travel with the row's record loads — L_*: the row whose first piece was requested last (its
+    // line_off / prefix_off entries, in flight); C_*: the row being picked (its prefix bytes were requested with its second piece, when
+    // L_* had landed); P_*: the finished row waiting to leave
+    uint64_t L_lo = 0ull, L_po = 0ull, L_po1 = 0ull, C_lo = 0ull, C_po = 0ull, C_plen = 0ull, P_lo = 0ull, P_po = 0ull, P_plen = 0ull;
+    uint32_t C_pfx = 0u, P_pfx = 0u;
+    auto load_offsets = [&](uint64_t row) {      // with piece 0 of `row`
+        if (lines) {
+            L_lo = a.line_off[row];
+            L_po = a.prefix_off[row];
+            L_po1 = a.prefix_off[row + 1ull];
+        }
+    };
+    auto load_prefix = [&]() {                    // with piece 1 of the same row: its offsets have landed (they are older than piece 0's data)
+        if (lines) {
+            C_lo = sgpr64_(L_lo);
+            C_po = sgpr64_(L_po);
+            C_plen = sgpr64_(L_po1) - C_po;
+            C_pfx = lane < C_plen ? (uint32_t)a.prefix_blob[C_po + lane] : 0u;
+        }
+    };
     // the row's text (and prefix) from its compact record in LDS
     auto emit_row = [&](uint64_t row) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -150,9 +175,17 @@ __global__ __launch_bounds__(kThreads) void gt_rowpick_kernel(EmitArgs a, ScanAr
         }
         uint8_t *row_out;
         if (lines) {
-            const uint64_t p0 = a.prefix_off[row], plen = a.prefix_off[row + 1ull] - p0;
-            uint8_t *const line = a.out + a.line_off[row];
-            for (uint64_t i = lane; i < plen; i += 64ull) line[i] = a.prefix_blob[p0 + i];   // :157-161
+            // the row's offsets came with its first piece and the first 64 bytes of its prefix with its second (P_*): nothing is
+            // fetched here unless the prefix is longer than a wave or the record has a single piece
+            uint64_t lo = P_lo, p0 = P_po, plen = P_plen;
+            if (n_seg < 2u) {
+                p0 = a.prefix_off[row];
+                plen = a.prefix_off[row + 1ull] - p0;
+                lo = a.line_off[row];
+            }
+            uint8_t *const line = a.out + lo;
+            if (n_seg >= 2u && lane < plen) line[lane] = (uint8_t)P_pfx;                                              // :157-161
+            for (uint64_t i = (n_seg >= 2u ? 64ull : 0ull) + lane; i < plen; i += 64ull) line[i] = a.prefix_blob[p0 + i];
             row_out = line + plen;
         } else {
             row_out = a.out + row * a.out_stride;
@@ -180,23 +213,35 @@ __global__ __launch_bounds__(kThreads) void gt_rowpick_kernel(EmitArgs a, ScanAr
     // is ever younger than the loads a wave waits for.
     bool pending = false;
     uint64_t pending_row = 0ull;
+    auto issue_next = [&](uint64_t p, v4u(&dst)[kTilesPerSeg]) {
+        advance(nrow, nseg);
+        const bool real = p + 1ull < pieces;                                        // (behind the last piece: a harmless re-load)
+        if (real && nseg == 0u) load_offsets(nrow);                                   // (in front of the piece's own loads: landed(piece) then covers them)
+        if (real && nseg == 1u) load_prefix();
+        load_piece(real ? nrow : row, real ? nseg : seg, dst);
+    };
+    auto finish_piece = [&]() {
+        if (seg + 1u == n_seg) {
+            pending = true;
+            pending_row = row;
+            P_lo = C_lo; P_po = C_po; P_plen = C_plen; P_pfx = C_pfx;
+        }
+        advance(row, seg);
+    };
+    load_offsets(nrow);
     load_piece(nrow, nseg, b0);
     for (uint64_t p = 0;;) {
         landed(b0);
         if (pending) { emit_row(pending_row); pending = false; }
-        advance(nrow, nseg);
-        load_piece(p + 1ull < pieces ? nrow : row, p + 1ull < pieces ? nseg : seg, b1);   // (behind the last piece: a harmless re-load)
+        issue_next(p, b1);
         pick_piece(seg, b0);
-        if (seg + 1u == n_seg) { pending = true; pending_row = row; }
-        advance(row, seg);
+        finish_piece();
         if (++p == pieces) break;
         landed(b1);
         if (pending) { emit_row(pending_row); pending = false; }
-        advance(nrow, nseg);
-        load_piece(p + 1ull < pieces ? nrow : row, p + 1ull < pieces ? nseg : seg, b0);
+        issue_next(p, b0);
         pick_piece(seg, b1);
-        if (seg + 1u == n_seg) { pending = true; pending_row = row; }
-        advance(row, seg);
+        finish_piece();
         if (++p == pieces) break;
     }
     if (pending) emit_row(pending_row);
