@@ -4,7 +4,7 @@
 //   pgen-hip query  <PFILE_PREFIX> -f|--fstring <EXPR> [-i|--include <EXPR>] [-s|--samples]
 //   pgen-hip filter <PFILE_PREFIX> [--include-var <EXPR>] [--include-sam <EXPR>] [-o|--out <FILE>]
 //
-// Additions (opt-in, not in the reference): --gpus <N>, --block-mib <M>, --filter-threads <T>, --stats, --dry-run
+// Additions (opt-in, not in the reference): --gpus <N>, --block-mib <M>, --launch-mib <M>, --filter-threads <T>, --stats, --dry-run
 // (filter: write the VCF header only and report the body geometry; needs no GPU); BGZF output (`-o x.vcf.gz` or --bgzf,
 // --bgzf-level <1-9>, --compress-threads <T>) and `pgen-hip bgzf <IN> <OUT>`, the same writer on a file.
 // Exit codes: 0 ok; 2 usage error (clap's code); 101 where the reference would panic.
@@ -96,7 +96,7 @@ const char *kUsage =
     "  help    Print this message\n\n"
     "query  <PFILE_PREFIX> -f, --fstring <QUERY_FSTRING> [-i, --include <QUERY>] [-s, --samples]\n"
     "filter <PFILE_PREFIX> [--include-var <VAR_QUERY>] [--include-sam <SAM_QUERY>] [-o, --out <OUT_FILE>]\n"
-    "       [--gpus <N>] [--shards <S>] [--block-mib <M>] [--write-threads <T>] [--read-threads <T>] [--filter-threads <T>] [--stats] [--dry-run]\n"
+    "       [--gpus <N>] [--shards <S>] [--block-mib <M>] [--launch-mib <M>] [--write-threads <T>] [--read-threads <T>] [--filter-threads <T>] [--stats] [--dry-run]\n"
     "       [--bgzf] [--bgzf-level <1-9>] [--compress-threads <T>]   (BGZF `.vcf.gz`; implied by an OUT_FILE ending in .gz)\n"
     "bgzf   <IN_FILE> <OUT_FILE> [--level <1-9>] [--threads <T>] [--chunk-mib <M>]\n";
 
@@ -225,7 +225,7 @@ int main(int argc, char **argv)
             return 0;
         }
         if (cmd == "filter") {  // src/main.rs:114-124
-            Args a = parse(argc, argv, 2, {{"include-var", 0}, {"include-sam", 0}, {"out", 'o'}, {"gpus", 0}, {"shards", 0}, {"block-mib", 0}, {"write-threads", 0}, {"read-threads", 0}, {"filter-threads", 0}, {"bgzf-level", 0}, {"compress-threads", 0}},
+            Args a = parse(argc, argv, 2, {{"include-var", 0}, {"include-sam", 0}, {"out", 'o'}, {"gpus", 0}, {"shards", 0}, {"block-mib", 0}, {"launch-mib", 0}, {"write-threads", 0}, {"read-threads", 0}, {"filter-threads", 0}, {"bgzf-level", 0}, {"compress-threads", 0}},
                            {{"stats", 0}, {"dry-run", 0}, {"bgzf", 0}});
             if (a.positional.size() != 1) usage_error("the following required arguments were not provided: <PFILE_PREFIX>");
             const Pfile pfile = Pfile::from_prefix(a.positional[0]);
@@ -266,6 +266,7 @@ int main(int argc, char **argv)
             if (auto w = a.get("write-threads")) opt.write_threads = std::max(1, std::atoi(w->c_str()));
             if (auto w = a.get("read-threads")) opt.read_threads = std::max(1, std::atoi(w->c_str()));
             if (auto m = a.get("block-mib")) opt.block_text_bytes = (uint64_t)std::max(1, std::atoi(m->c_str())) << 20;
+            if (auto m = a.get("launch-mib")) opt.launch_bytes = (uint64_t)std::max(1, std::atoi(m->c_str())) << 20;
             const OutputStats st = pfile.output_vcf(a.get("include-sam"), a.get("include-var"), out_file, opt);  // :123
             if (a.has("stats")) {
                 std::fprintf(stderr,

@@ -349,7 +349,7 @@ namespace {
 
 struct DeviceBuffers {
     pgenhip_ctx *ctx = nullptr;
-    void *h_rec = nullptr, *h_blob = nullptr, *h_off = nullptr, *h_text = nullptr;
+    void *h_rec = nullptr, *h_blob = nullptr, *h_off = nullptr, *h_text = nullptr, *h_text2 = nullptr;
     void *d_rec = nullptr, *d_blob = nullptr, *d_off = nullptr, *d_text = nullptr;
     ~DeviceBuffers()
     {
@@ -358,6 +358,7 @@ struct DeviceBuffers {
         pgenhip_host_free_pinned(ctx, h_blob);
         pgenhip_host_free_pinned(ctx, h_off);
         pgenhip_host_free_pinned(ctx, h_text);
+        pgenhip_host_free_pinned(ctx, h_text2);
         pgenhip_device_free(ctx, d_rec);
         pgenhip_device_free(ctx, d_blob);
         pgenhip_device_free(ctx, d_off);
@@ -523,34 +524,62 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
             // samples (little text per record) still moves in several blocks and its file reads overlap the copies and the kernel
             const uint64_t max_line = max_prefix + 4ull * K + 1ull;
             const uint64_t bv = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(opt.block_text_bytes / max_line, opt.block_text_bytes / std::max<uint32_t>(R, 1u)), end - begin));
+            const size_t n_blocks = (end - begin + (size_t)bv - 1) / (size_t)bv;
+            // A block is the unit of file staging, of the D2H copy and of the file write.  A LAUNCH covers several consecutive blocks
+            // (up to the launch budget of text or record bytes): its records are staged block by block while the blocks of the launch
+            // before it are copied out and written, so the host pipeline keeps the cadence of small blocks and the kernel sees launches
+            // of up to 2 GiB (a 128-MiB launch of the chr22 shape is two work items deep: 39 us where its share of a large launch costs
+            // 25 us, profiles/r03_cli_kernels.md).  Launch sizes ramp 1, 2, 4, ... blocks so the first byte leaves as early as before.
+            const uint64_t blocks_per_launch_max = std::max<uint64_t>(1, std::min<uint64_t>(opt.launch_bytes / std::max<uint64_t>(1, std::max<uint64_t>(bv * max_line, bv * R)), n_blocks));
+            struct LaunchPlan {
+                size_t first_block, n_blocks;
+            };
+            std::vector<LaunchPlan> plan;
+            size_t widest = 1;
+            for (size_t k = 0, step = 1; k < n_blocks; step = (size_t)std::min<uint64_t>(2 * (uint64_t)step, blocks_per_launch_max)) {
+                const size_t n = (size_t)std::min<uint64_t>(std::min<uint64_t>(step, blocks_per_launch_max), n_blocks - k);
+                plan.push_back(LaunchPlan{k, n});
+                widest = std::max(widest, n);
+                k += n;
+            }
+            const uint64_t lv = std::min<uint64_t>(bv * widest, end - begin);   // variants of the widest launch
             const size_t rec_bytes = (size_t)(bv * R), blob_bytes = (size_t)(bv * max_prefix), text_bytes = (size_t)(bv * max_line);
             const size_t off_bytes = (size_t)(2 * (bv + 1) * sizeof(uint64_t));
-            const size_t n_blocks = (end - begin + (size_t)bv - 1) / (size_t)bv;
-            const int n_sets = n_blocks > 1 ? 2 : 1;
+            const int n_sets = plan.size() > 1 ? 2 : 1;     // device-side sets (one launch each), each with its own ctx / stream
+            const int n_text = n_blocks > 1 ? 2 : 1;        // pinned text buffers (one block each)
             DeviceBuffers sets[2];
+            void *h_text[2] = {nullptr, nullptr};
             for (int s = 0; s < n_sets; s++) {
                 DeviceBuffers &B = sets[s];
                 // a filter that kept NOBODY is an empty list, not "all samples": say so with the flag (kept.data() is NULL then)
                 check(pgenhip_create(&B.ctx, g % n_use, N, all_samples ? nullptr : kept.data(), (uint32_t)K,
                                      all_samples ? 0u : PGENHIP_CREATE_KEEP_LIST), "pgenhip_create");
-                check(pgenhip_host_malloc_pinned(B.ctx, &B.h_rec, rec_bytes), "pinned records");
-                check(pgenhip_host_malloc_pinned(B.ctx, &B.h_blob, blob_bytes), "pinned prefixes");
-                check(pgenhip_host_malloc_pinned(B.ctx, &B.h_off, off_bytes), "pinned offsets");
-                check(pgenhip_host_malloc_pinned(B.ctx, &B.h_text, text_bytes), "pinned text");
-                check(pgenhip_device_malloc(B.ctx, &B.d_rec, rec_bytes), "device records");
-                check(pgenhip_device_malloc(B.ctx, &B.d_blob, blob_bytes), "device prefixes");
-                check(pgenhip_device_malloc(B.ctx, &B.d_off, off_bytes), "device offsets");
-                check(pgenhip_device_malloc(B.ctx, &B.d_text, text_bytes), "device text");
+                check(pgenhip_device_malloc(B.ctx, &B.d_rec, (size_t)(lv * R)), "device records");
+                check(pgenhip_device_malloc(B.ctx, &B.d_blob, (size_t)(lv * max_prefix)), "device prefixes");
+                check(pgenhip_device_malloc(B.ctx, &B.d_off, (size_t)(2 * (lv + 1) * sizeof(uint64_t))), "device offsets");
+                check(pgenhip_device_malloc(B.ctx, &B.d_text, (size_t)(lv * max_line)), "device text");
+            }
+            // pinned staging: ONE set of input buffers (each block's H2D is waited for before the next block is staged) ...
+            check(pgenhip_host_malloc_pinned(sets[0].ctx, &sets[0].h_rec, rec_bytes), "pinned records");
+            check(pgenhip_host_malloc_pinned(sets[0].ctx, &sets[0].h_blob, blob_bytes), "pinned prefixes");
+            check(pgenhip_host_malloc_pinned(sets[0].ctx, &sets[0].h_off, off_bytes), "pinned offsets");
+            // ... and two text buffers (freed with the sets: DeviceBuffers owns h_text)
+            for (int t = 0; t < n_text; t++) {
+                check(pgenhip_host_malloc_pinned(sets[0].ctx, &h_text[t], text_bytes), "pinned text");
+                (t == 0 ? sets[0].h_text : sets[0].h_text2) = h_text[t];
             }
             struct InFlight {
-                int set;
+                int text;      // pinned text buffer
+                int set;       // device set (stream) the copy was queued on
+                bool first;    // first block of its launch: the kernel's time is read here
                 size_t b0;
                 uint64_t bytes;
             };
             std::mutex mu;
             std::condition_variable cv;
             std::deque<InFlight> inflight;
-            bool set_busy[2] = {false, false};
+            bool text_busy[2] = {false, false};
+            uint64_t pushed[2] = {0, 0}, consumed[2] = {0, 0};   // blocks per device set
             bool producer_done = false;
             std::string consumer_err;
 
@@ -568,10 +597,10 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                         DeviceBuffers &B = sets[job.set];
                         check(pgenhip_wait(B.ctx), "pgenhip_wait");
                         float ms = 0;
-                        if (pgenhip_timer_read(B.ctx, &ms) == PGENHIP_OK) kernel_s[(size_t)g] += ms * 1e-3;
+                        if (job.first && pgenhip_timer_read(B.ctx, &ms) == PGENHIP_OK) kernel_s[(size_t)g] += ms * 1e-3;
                         // every line has a known length, so ranges land at precomputed offsets in any order
                         const uint64_t file_pos = header.size() + file_off[job.b0];
-                        const uint8_t *text = static_cast<const uint8_t *>(B.h_text);
+                        const uint8_t *text = static_cast<const uint8_t *>(h_text[job.text]);
                         if (zw) {
                             zw->write(text, (size_t)job.bytes);   // blocks arrive in order: the members are appended in order
                         } else if (n_writers <= 1 || job.bytes < (8ull << 20)) {
@@ -598,14 +627,15 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                         }
                         {
                             std::lock_guard<std::mutex> lk(mu);
-                            set_busy[job.set] = false;
+                            text_busy[job.text] = false;
+                            consumed[job.set]++;
                         }
                         cv.notify_all();
                     }
                 } catch (const std::exception &e) {
                     std::lock_guard<std::mutex> lk(mu);
                     consumer_err = e.what();
-                    set_busy[0] = set_busy[1] = false;
+                    text_busy[0] = text_busy[1] = false;
                     cv.notify_all();
                 }
             });
@@ -625,34 +655,33 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                 }
             } joiner{consumer, mu, cv, producer_done};
 
-            size_t k = 0;
-            for (size_t b0 = begin; b0 < end; b0 += (size_t)bv, k++) {
-                const int si = (int)(k % (size_t)n_sets);
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return !set_busy[si] || !consumer_err.empty(); });
-                    if (!consumer_err.empty()) throw PfileError(consumer_err);
-                    set_busy[si] = true;
-                }
-                DeviceBuffers &B = sets[si];
-                uint8_t *h_rec = static_cast<uint8_t *>(B.h_rec);
-                char *h_blob = static_cast<char *>(B.h_blob);
-                uint64_t *h_poff = static_cast<uint64_t *>(B.h_off);
-                uint64_t *h_loff = h_poff + (bv + 1);
+            uint8_t *h_rec = static_cast<uint8_t *>(sets[0].h_rec);
+            char *h_blob = static_cast<char *>(sets[0].h_blob);
+            uint64_t *h_poff = static_cast<uint64_t *>(sets[0].h_off);
+            uint64_t *h_loff = h_poff + (bv + 1);
+            std::vector<uint64_t> blob_len(plan.size(), 0);   // prefix bytes staged so far, per launch
+            auto launch_b0 = [&](size_t u) { return begin + plan[u].first_block * (size_t)bv; };
+            auto launch_nv = [&](size_t u) { return std::min<size_t>(plan[u].n_blocks * (size_t)bv, end - launch_b0(u)); };
+
+            // block j of launch u: records from the file, prefixes joined, offsets — into the pinned staging set, then to their place
+            // in the launch's device buffers (on the launch's own stream, idle by now: see the wait in the schedule below)
+            auto stage_block = [&](size_t u, size_t j) {
+                DeviceBuffers &B = sets[u % (size_t)n_sets];
+                const size_t r0 = j * (size_t)bv, b0 = launch_b0(u) + r0;
                 const size_t nv = std::min<size_t>((size_t)bv, end - b0);
                 // :165-170 once per run of consecutive variant indices instead of once per variant
-                for (size_t j = 0; j < nv;) {
+                for (size_t j2 = 0; j2 < nv;) {
                     size_t run = 1;
                     // (variable-width files: consecutive plain records are adjacent on disk too when nothing compressed lies between them)
-                    while (j + run < nv && var_idx_rcds[b0 + j + run].first == var_idx_rcds[b0 + j].first + run &&
-                           record_offset(var_idx_rcds[b0 + j + run].first) == record_offset(var_idx_rcds[b0 + j].first) + run * (uint64_t)R)
+                    while (j2 + run < nv && var_idx_rcds[b0 + j2 + run].first == var_idx_rcds[b0 + j2].first + run &&
+                           record_offset(var_idx_rcds[b0 + j2 + run].first) == record_offset(var_idx_rcds[b0 + j2].first) + run * (uint64_t)R)
                         run++;
                     // (a long run is read by a few threads at once: one thread copies ~2-3 GB/s out of the page cache)
                     const size_t run_bytes = run * (size_t)R;
-                    const uint64_t run_off = record_offset(var_idx_rcds[b0 + j].first);
+                    const uint64_t run_off = record_offset(var_idx_rcds[b0 + j2].first);
                     const unsigned n_readers = run_bytes >= (64u << 20) ? (unsigned)std::max(1, opt.read_threads) : 1u;
                     if (n_readers <= 1) {
-                        pread_exact(pfd, h_rec + j * R, run_bytes, run_off, pgen);
+                        pread_exact(pfd, h_rec + j2 * R, run_bytes, run_off, pgen);
                     } else {
                         std::vector<std::thread> rs;
                         std::string rerr;
@@ -663,7 +692,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                             if (lo == hi) continue;
                             rs.emplace_back([&, lo, hi] {
                                 try {
-                                    pread_exact(pfd, h_rec + j * R + lo, hi - lo, run_off + lo, pgen);
+                                    pread_exact(pfd, h_rec + j2 * R + lo, hi - lo, run_off + lo, pgen);
                                 } catch (const std::exception &e) {
                                     std::lock_guard<std::mutex> lk(rmu);
                                     rerr = e.what();
@@ -673,14 +702,15 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                         for (auto &t : rs) t.join();
                         if (!rerr.empty()) throw PfileError(rerr);
                     }
-                    j += run;
+                    j2 += run;
                 }
-                // :157-161 joined once per variant: col '\t' col '\t' ... "GT"
+                // :157-161 joined once per variant: col '\t' col '\t' ... "GT"; offsets count from the start of the LAUNCH's blob / text
+                const uint64_t blob0 = blob_len[u], text0 = file_off[launch_b0(u)];
                 uint64_t bp = 0;
-                for (size_t j = 0; j < nv; j++) {
-                    h_poff[j] = bp;
-                    h_loff[j] = file_off[b0 + j] - file_off[b0];
-                    for (const auto &col : var_idx_rcds[b0 + j].second) {
+                for (size_t i = 0; i < nv; i++) {
+                    h_poff[i] = blob0 + bp;
+                    h_loff[i] = file_off[b0 + i] - text0;
+                    for (const auto &col : var_idx_rcds[b0 + i].second) {
                         std::memcpy(h_blob + bp, col.data(), col.size());
                         bp += col.size();
                         h_blob[bp++] = '\t';
@@ -688,23 +718,65 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                     h_blob[bp++] = 'G';
                     h_blob[bp++] = 'T';
                 }
-                h_poff[nv] = bp;
-                const uint64_t block_bytes = file_off[b0 + nv] - file_off[b0];
-                h_loff[nv] = block_bytes;
-                check(pgenhip_memcpy_h2d(B.ctx, B.d_rec, h_rec, nv * (size_t)R), "H2D records");
-                check(pgenhip_memcpy_h2d(B.ctx, B.d_blob, h_blob, (size_t)bp), "H2D prefixes");
-                check(pgenhip_memcpy_h2d(B.ctx, B.d_off, h_poff, off_bytes), "H2D offsets");
+                h_poff[nv] = blob0 + bp;                       // (the next block's first entry, or the launch's end)
+                h_loff[nv] = file_off[b0 + nv] - text0;
+                blob_len[u] = blob0 + bp;
+                uint64_t *d_poff = static_cast<uint64_t *>(B.d_off), *d_loff = d_poff + (lv + 1);
+                check(pgenhip_memcpy_h2d(B.ctx, static_cast<uint8_t *>(B.d_rec) + r0 * (size_t)R, h_rec, nv * (size_t)R), "H2D records");
+                check(pgenhip_memcpy_h2d(B.ctx, static_cast<char *>(B.d_blob) + blob0, h_blob, (size_t)bp), "H2D prefixes");
+                check(pgenhip_memcpy_h2d(B.ctx, d_poff + r0, h_poff, (nv + 1) * sizeof(uint64_t)), "H2D prefix offsets");
+                check(pgenhip_memcpy_h2d(B.ctx, d_loff + r0, h_loff, (nv + 1) * sizeof(uint64_t)), "H2D line offsets");
+                check(pgenhip_wait(B.ctx), "pgenhip_wait");   // the staging set is free again
+            };
+            auto launch = [&](size_t u) {
+                DeviceBuffers &B = sets[u % (size_t)n_sets];
+                uint64_t *d_poff = static_cast<uint64_t *>(B.d_off), *d_loff = d_poff + (lv + 1);
                 check(pgenhip_timer_start(B.ctx), "timer");
-                check(pgenhip_emit_lines(B.ctx, B.d_rec, R, nullptr, (uint32_t)nv, B.d_blob, static_cast<uint64_t *>(B.d_off),
-                                         static_cast<uint64_t *>(B.d_off) + (bv + 1), max_prefix, B.d_text, 0),
-                      "pgenhip_emit_lines");
+                check(pgenhip_emit_lines(B.ctx, B.d_rec, R, nullptr, (uint32_t)launch_nv(u), B.d_blob, d_poff, d_loff, max_prefix, B.d_text, 0), "pgenhip_emit_lines");
                 check(pgenhip_timer_mark(B.ctx), "timer");
-                check(pgenhip_memcpy_d2h(B.ctx, B.h_text, B.d_text, (size_t)block_bytes), "D2H text");
+            };
+            // block j of launch u leaves: D2H into a free pinned text buffer, then the consumer's
+            auto drain_block = [&](size_t u, size_t j) {
+                const int si = (int)(u % (size_t)n_sets), ti = (int)((plan[u].first_block + j) % (size_t)n_text);
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !text_busy[ti] || !consumer_err.empty(); });
+                    if (!consumer_err.empty()) throw PfileError(consumer_err);
+                    text_busy[ti] = true;
+                }
+                const size_t b0 = launch_b0(u) + j * (size_t)bv, nv = std::min<size_t>((size_t)bv, end - b0);
+                const uint64_t block_bytes = file_off[b0 + nv] - file_off[b0];
+                check(pgenhip_memcpy_d2h(sets[si].ctx, h_text[ti], static_cast<uint8_t *>(sets[si].d_text) + (file_off[b0] - file_off[launch_b0(u)]), (size_t)block_bytes), "D2H text");
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    inflight.push_back(InFlight{si, b0, block_bytes});
+                    inflight.push_back(InFlight{ti, si, j == 0, b0, block_bytes});
+                    pushed[si]++;
                 }
                 cv.notify_all();
+            };
+            // a device set is staged into again only once every block of its previous launch has been written: its stream is idle
+            // then, so the producer's waits in stage_block never meet the consumer's on the same stream
+            auto wait_set_idle = [&](size_t u) {
+                const int si = (int)(u % (size_t)n_sets);
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return consumed[si] == pushed[si] || !consumer_err.empty(); });
+                if (!consumer_err.empty()) throw PfileError(consumer_err);
+            };
+
+            for (size_t j = 0; j < plan[0].n_blocks; j++) stage_block(0, j);
+            launch(0);
+            for (size_t u = 0; u < plan.size(); u++) {
+                const size_t n_u = plan[u].n_blocks, n_next = u + 1 < plan.size() ? plan[u + 1].n_blocks : 0;
+                size_t staged = 0;
+                for (size_t j = 0; j < n_u; j++) {
+                    drain_block(u, j);
+                    // the next launch's share of staging, so that it is complete when this launch's last block has been queued
+                    while (staged < n_next && staged * n_u < (j + 1) * n_next) {
+                        if (staged == 0) wait_set_idle(u + 1);
+                        stage_block(u + 1, staged++);
+                    }
+                }
+                if (n_next) launch(u + 1);
             }
             {
                 std::unique_lock<std::mutex> lk(mu);

@@ -24,9 +24,10 @@ struct PfileError : std::runtime_error {
 struct OutputOptions {
     int n_gpus = 1;                         // variant ranges shard over devices 0..n_gpus-1 (no collective)
     int n_shards = 0;                       // 0 = one shard per GPU; > 0: that many variant ranges, dealt round-robin over the GPUs
-    uint64_t block_text_bytes = 128ull << 20;  // VCF bytes produced (and record bytes read) per launch and device.  End to end on the chr22 shape
+    uint64_t block_text_bytes = 128ull << 20;  // VCF bytes produced (and record bytes read) per block and device: the unit of staging, D2H copy and file write.  End to end on the chr22 shape
                                                // (tmpfs): 512 / 256 / 128 / 64 MiB -> 2.87 / 2.56 / 2.47 / 2.39 s keeping everybody, 1.03 / 0.76 / 0.65 / 0.65 s
                                                // keeping 20 samples: pinning the staging buffers costs more than bigger launches give (profiles/r02_e2e.md)
+    uint64_t launch_bytes = 2048ull << 20;     // text (or record) bytes one kernel launch covers: several consecutive blocks, staged and copied out block by block
     int write_threads = 1;                  // parallel pwrite()s per block and device
     int read_threads = 4;                   // parallel pread()s of one run of consecutive records (runs of >= 64 MiB)
     bool bgzf = false;                      // write BGZF (`.vcf.gz`) instead of plain text

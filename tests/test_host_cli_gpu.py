@@ -21,7 +21,7 @@ CLI = REPO / "pgen_rs_amd" / "pgen-hip"
 
 
 def run(*args):
-    return subprocess.run([str(CLI), *args], capture_output=True)
+    return subprocess.run([str(CLI), *args], capture_output=True, timeout=300)
 
 
 @pytest.fixture(scope="module")
@@ -151,6 +151,22 @@ def test_basic2_whole_file(basic2, tmp_path):
     p = run("filter", str(basic2), "-o", str(out), "--block-mib", "64")
     assert p.returncode == 0, p.stderr
     want = expected_vcf(basic2)
+    got = out.read_bytes()
+    assert len(got) == len(want) and hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
+
+
+@pytest.mark.parametrize("block_mib,launch_mib,extra", [(1, 1, []), (4, 4, []), (4, 24, []), (2, 1024, []), (8, 40, ["--shards", "3"]), (4, 32, ["--write-threads", "3"]),
+                                                         (1, 16, ["--include-sam", 'IID != "per7"', "--include-var", 'ALT == "G"'])])
+def test_basic2_launches_of_several_blocks(basic2, tmp_path, block_mib, launch_mib, extra):
+    """A launch covers several blocks (`--launch-mib` / `--block-mib` = 1 (245 launches), 1, 6, all, 5, 8, 16 blocks, ramping 1, 2, 4, ...): the
+    blocks are staged into, and copied out of, their places in the launch's buffers one by one.  Same bytes for every split."""
+    out = tmp_path / "l.vcf"
+    p = run("filter", str(basic2), "-o", str(out), "--block-mib", str(block_mib), "--launch-mib", str(launch_mib), *extra)
+    assert p.returncode == 0, p.stderr
+    if "--include-sam" in extra:
+        want = expected_vcf(basic2, var_pred=lambda r: r[b"ALT"] == b"G", sam_pred=lambda r: r[b"IID"] != b"per7")
+    else:
+        want = expected_vcf(basic2)
     got = out.read_bytes()
     assert len(got) == len(want) and hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
 
