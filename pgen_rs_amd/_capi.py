@@ -57,6 +57,8 @@ KNOB_SCAN_CHUNK_ROWS = 10
 KNOB_ROWPICK_BLOCKS_PER_CU = 11
 KNOB_SCAN_ROWPICK = 12
 KNOB_PICK_LINE_SEAMS = 13
+KNOB_FLUSH_UNROLL = 14
+KNOB_SCAN_TEXT_MODE = 15
 
 
 

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace pgenhip {
@@ -148,7 +150,11 @@ __device__ __forceinline__ uint8_t *row_text(const EmitArgs &a, uint64_t j)
 // whoever writes the neighbouring bytes) go out as ONE byte-store instruction: lanes 0-15 the head bytes, lanes
 // 16-31 the tail bytes.  All 64-bit arithmetic is wave-uniform (scalar unit); a lane only adds a 32-bit offset.
 // `code_of(x)` yields the 2-bit code at position x = base + segment rank (ring position, or rank for the pick kernel).
-template <typename CodeFn>
+// U chunks per lane and loop step: their 5 U table reads, then their 5 U staged-byte reads leave together, so a step costs two LDS
+// round trips whatever U is (the compiler does not unroll this loop by itself; with the segment kernel's two waves per SIMD the
+// round trips of U = 1 are exposed).
+// TEXT: `code_of` already yields the genotype's text dword (a kernel with a byte -> text table in LDS) instead of its 2-bit code.
+template <uint32_t U = 1, bool TEXT = false, typename CodeFn>
 __device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
                                             uint32_t seg_k0, uint32_t K, uint32_t lane)
 {
@@ -163,27 +169,114 @@ __device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8
     const uint32_t em = (uint32_t)emitted & 3u;
     const uint64_t nl64 = 4ull * K - emitted;                          // flush offset of the row's '\n' (row byte 4K)
     const uint32_t nl = nl64 < (uint64_t)len ? (uint32_t)nl64 : 0xFFFFFFFFu;
-    for (uint32_t i = lane; i < n_chunks; i += 64u) {
-        const uint32_t off = head + (i << 4);
-        const uint32_t x = em + off;                                   // byte offset from the dword boundary under `emitted`
-        const uint32_t rel = e4 + (x >> 2);
-        const uint32_t sh = x & 3u;
-        const uint32_t t0 = gt_text(code_of(rel));
-        const uint32_t t1 = gt_text(code_of(rel + 1u));
-        const uint32_t t2 = gt_text(code_of(rel + 2u));
-        const uint32_t t3 = gt_text(code_of(rel + 3u));
-        const uint32_t t4 = gt_text(code_of(rel + 4u));  // may be past the flush: then it feeds no byte (sh = 0) or only '\n''s place
-        gt_v4u v = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
-        // the row's '\n' can only be a whole chunk's last byte (hi_emit <= 4K + 1)
-        if (off + 15u == nl) v.w = (v.w & 0x00FFFFFFu) | 0x0A000000u;
-        *reinterpret_cast<gt_v4u *>(out0 + off) = v;
+    for (uint32_t i0 = 0; i0 < n_chunks; i0 += 64u * U) {
+        uint32_t offv[U], shv[U], c[U][5];
+        bool ok[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t i = i0 + u * 64u + lane;
+            ok[u] = i < n_chunks;
+            offv[u] = head + ((ok[u] ? i : 0u) << 4);                  // (a lane without a chunk re-reads chunk 0's codes and stores nothing)
+            const uint32_t x = em + offv[u];                           // byte offset from the dword boundary under `emitted`
+            const uint32_t rel = e4 + (x >> 2);
+            shv[u] = x & 3u;
+#pragma unroll
+            for (uint32_t k = 0; k < 5u; k++) c[u][k] = code_of(rel + k);  // the fifth may be past the flush: then it feeds no byte (sh = 0) or only '\n''s place
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t t0 = TEXT ? c[u][0] : gt_text(c[u][0]), t1 = TEXT ? c[u][1] : gt_text(c[u][1]), t2 = TEXT ? c[u][2] : gt_text(c[u][2]),
+                           t3 = TEXT ? c[u][3] : gt_text(c[u][3]), t4 = TEXT ? c[u][4] : gt_text(c[u][4]);
+            const uint32_t sh = shv[u];
+            gt_v4u v = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
+            // the row's '\n' can only be a whole chunk's last byte (hi_emit <= 4K + 1)
+            if (offv[u] + 15u == nl) v.w = (v.w & 0x00FFFFFFu) | 0x0A000000u;
+            if (ok[u]) *reinterpret_cast<gt_v4u *>(out0 + offv[u]) = v;
+        }
     }
     const uint32_t off = lane < 16u ? lane : tail_off + (lane - 16u);
     const bool on = lane < 16u ? lane < head : (lane < 32u && lane - 16u < tail);
     if (on) {
         const uint32_t x = em + off;
         const uint32_t code = code_of(e4 + (x >> 2));
-        out0[off] = (uint8_t)(off == nl ? 0x0Au : gt_text_byte(code, x & 3u));
+        out0[off] = (uint8_t)(off == nl ? 0x0Au : TEXT ? (code >> (8u * (x & 3u))) & 0xFFu : gt_text_byte(code, x & 3u));
+    }
+}
+
+// The same flush for kernels whose picks come four at a time.  A 16-byte chunk holds the text of ranks rel .. rel+3 and, when the
+// flush's phase is not zero, leading bytes of rank rel+4 — which is the FIRST rank of the next chunk, i.e. of the next lane: it comes
+// over by a wavefront shift (v_mov_b32_dpp wave_shl:1) instead of a fifth pick, lane 63's from the next group of 64 chunks (one
+// extra single pick per step, for the chunk behind the step).  The four table entries of a chunk are consecutive:
+// `texts4(c0, g, t0..t3)` gets the flush-uniform C0 = rel & 3 as a std::integral_constant (four copies of the loop, chosen per flush by
+// a scalar branch) and the aligned group g = rel >> 2, and returns the texts of ranks 4g + C0 .. 4g + C0 + 3; `text1(rel)` returns one.
+// Lane <-> chunk: lane l of group u of a step takes chunk i0 + 64 u + l - lead, where `lead` = the chunks between the 128-byte line
+// boundary at or below chunk 0 and chunk 0: every store instruction then covers eight WHOLE lines (a store that starts mid-line
+// touches nine, two of them partially: -5 % on write-dominated launches).  `part` of `n_parts` cooperating waves takes the steps
+// part, part + n_parts, ...: together they write 64 U n_parts chunks of contiguous text per round.
+template <uint32_t U, uint32_t C0, typename Text4Fn, typename Text1Fn>
+__device__ __forceinline__ void flush_text4_loop(Text4Fn texts4, Text1Fn text1, uint8_t *out0, uint32_t head, uint32_t n_chunks, uint32_t rel0,
+                                                 uint32_t sh, uint32_t rmax, uint32_t nl, uint32_t lane, uint32_t part, uint32_t n_parts)
+{
+    const uint32_t lead = __builtin_amdgcn_readfirstlane(((uint32_t)(uintptr_t)(out0 + head) >> 4) & 7u);
+    const uint32_t t_last = text1(rmax);                                // the rank behind the last whole chunk
+    for (uint32_t i0 = part * 64u * U; i0 < n_chunks + lead; i0 += n_parts * 64u * U) {
+        uint32_t t[U][5], offv[U];
+        bool ok[U], last[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t i = i0 + u * 64u + lane - lead;              // (wraps for the lanes in front of chunk 0: not ok)
+            ok[u] = i < n_chunks;
+            last[u] = i + 1u == n_chunks;
+            const uint32_t ii = ok[u] ? i : 0u;                         // (a lane without a chunk re-reads chunk 0's entries and stores nothing)
+            offv[u] = head + (ii << 4);
+            texts4(std::integral_constant<uint32_t, C0>{}, (rel0 >> 2) + ii, t[u][0], t[u][1], t[u][2], t[u][3]);
+        }
+        const uint32_t t_next = text1(min(rel0 + 4u * (i0 + 64u * U - lead), rmax));   // first rank of the chunk behind this step (wave-uniform)
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t from_next_lane = __builtin_amdgcn_update_dpp(0u, t[u][0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+            const uint32_t from_next_group = u + 1u < U ? (uint32_t)__builtin_amdgcn_readfirstlane(t[u + 1u < U ? u + 1u : u][0]) : t_next;
+            t[u][4] = last[u] ? t_last : lane == 63u ? from_next_group : from_next_lane;
+            gt_v4u v = {funnel_bytes(t[u][0], t[u][1], sh), funnel_bytes(t[u][1], t[u][2], sh), funnel_bytes(t[u][2], t[u][3], sh), funnel_bytes(t[u][3], t[u][4], sh)};
+            if (offv[u] + 15u == nl) v.w = (v.w & 0x00FFFFFFu) | 0x0A000000u;   // the row's '\n' can only be a whole chunk's last byte
+            if (ok[u]) *reinterpret_cast<gt_v4u *>(out0 + offv[u]) = v;
+        }
+    }
+}
+
+template <uint32_t U, typename Text4Fn, typename Text1Fn>
+__device__ __forceinline__ void flush_text4(Text4Fn texts4, Text1Fn text1, uint32_t base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
+                                            uint32_t seg_k0, uint32_t K, uint32_t lane, uint32_t part = 0u, uint32_t n_parts = 1u)
+{
+    uint8_t *const out0 = row_out + emitted;
+    const uint32_t len = (uint32_t)(hi_emit - emitted);
+    const uint32_t mis = (uint32_t)(uintptr_t)out0 & 15u;
+    const uint32_t head = min((16u - mis) & 15u, len);
+    const uint32_t n_chunks = (len - head) >> 4;
+    const uint32_t tail_off = head + (n_chunks << 4);
+    const uint32_t tail = len - tail_off;
+    const uint32_t e4 = base + (uint32_t)(emitted >> 2) - seg_k0;
+    const uint32_t em = (uint32_t)emitted & 3u;
+    const uint64_t nl64 = 4ull * K - emitted;
+    const uint32_t nl = nl64 < (uint64_t)len ? (uint32_t)nl64 : 0xFFFFFFFFu;
+    if (n_chunks != 0u) {
+        const uint32_t x0 = em + head;                                  // byte offset of chunk 0 from the dword boundary under `emitted`
+        const uint32_t rel0 = __builtin_amdgcn_readfirstlane(e4 + (x0 >> 2));
+        const uint32_t sh = __builtin_amdgcn_readfirstlane(x0 & 3u);
+        const uint32_t rmax = __builtin_amdgcn_readfirstlane(e4 + ((em + tail_off) >> 2));
+        switch (rel0 & 3u) {
+            case 0u: flush_text4_loop<U, 0>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts); break;
+            case 1u: flush_text4_loop<U, 1>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts); break;
+            case 2u: flush_text4_loop<U, 2>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts); break;
+            default: flush_text4_loop<U, 3>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts); break;
+        }
+    }
+    if (part != 0u) return;                                             // the edges: the first of the cooperating waves
+    const uint32_t off = lane < 16u ? lane : tail_off + (lane - 16u);
+    const bool on = lane < 16u ? lane < head : (lane < 32u && lane - 16u < tail);
+    if (on) {
+        const uint32_t x = em + off;
+        out0[off] = (uint8_t)(off == nl ? 0x0Au : (text1(e4 + (x >> 2)) >> (8u * (x & 3u))) & 0xFFu);
     }
 }
 

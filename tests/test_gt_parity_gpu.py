@@ -1227,3 +1227,31 @@ def test_gt_segments_past_4_gib(n, v, keep_frac, pad):
                 bad = np.argwhere(got != want)
                 raise AssertionError(f"n={n} k={k} rows {j0}..{j1}: {bad.shape[0]} bytes differ, first at row/col {bad[:4].tolist()}")
         del out, rows2d
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("unroll", [1, 2, 4])
+def test_segment_kernel_text_modes_and_flush_unrolls(mode, unroll):
+    """The segment kernel's ways of turning (table entry, staged record byte) into text — shifts + arithmetic, the byte -> text
+    table in LDS, bit-field extract — with 1 / 2 / 4 chunks per lane and flush step: same bytes as the oracle for ragged record
+    tails, segments with 0 / 1 / all samples kept, every row alignment (odd K), with and without a gathered variant list."""
+    rng = np.random.default_rng(1000 + 10 * mode + unroll)
+    for n, dens, v in ((16385, 0.5, 37), (40_001, 0.93, 23), (70_003, 0.07, 29), (33_000, 1.0, 11)):
+        r = oracle.variant_record_size(n)
+        keep = rng.random(n) < dens
+        keep[16384:16384 + 900] = False          # a stretch without kept samples across a segment boundary
+        if n > 33_000:
+            keep[32768:32768 + 16384] = n % 2 == 0    # a segment that is empty (or wholly kept)
+        kept = np.flatnonzero(keep).astype(np.uint32)
+        if kept.size == n:
+            kept = kept[:-1]
+        recs = rng.integers(0, 256, size=2 * v * r, dtype=np.uint8)
+        vidx = rng.permutation(2 * v)[:v]
+        tune = {_capi.KNOB_SCAN_TEXT_MODE: mode, _capi.KNOB_FLUSH_UNROLL: unroll, _capi.KNOB_SCAN_BLOCKS_PER_CU: 1}
+        got, k = run_engine(recs, v, n, kept=kept, kernel=_capi.KERNEL_SCAN, tune=tune)
+        want = oracle.decode_emit(recs[: v * r], v, n, kept_idx=kept)
+        assert bytes(got[: want.size]) == want.tobytes(), (n, dens)
+        assert (got[want.size :] == SENTINEL).all()
+        got, k = run_engine(recs, v, n, kept=kept, kernel=_capi.KERNEL_SCAN, tune=tune, variant_idx=vidx)
+        want = oracle.decode_emit(recs.reshape(2 * v, r)[vidx].reshape(-1), v, n, kept_idx=kept)
+        assert bytes(got[: want.size]) == want.tobytes(), (n, dens, "gathered")

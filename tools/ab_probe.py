@@ -37,11 +37,18 @@ def main():
     ap.add_argument("--gather", action="store_true", help="rows through a variant index list (every other record of a file twice as long)")
     ap.add_argument("--lines", type=int, default=0, metavar="PREFIX_BYTES",
                     help="full VCF body lines (pgenhip_emit_lines) with synthetic prefixes of about this many bytes instead of GT segments")
+    ap.add_argument("--keep-stride", type=int, default=0, help="regular kept subset: every S-th sample")
+    ap.add_argument("--align-lines", type=int, default=0, metavar="A", help="with --lines: every line starts at a multiple of A bytes (gaps between lines stay unwritten)")
+    ap.add_argument("--fold-rows", type=int, default=0, metavar="W",
+                    help="with --lines: line j is written where line j %% W would go, so the whole launch writes one small window again and again "
+                         "(what the kernel can issue when the memory side absorbs its writes; the output is garbage)")
     args = ap.parse_args()
     n, v = args.samples, args.variants
     kept = None
     if args.keep_frac > 0:
         kept = np.sort(np.random.default_rng(1).choice(n, size=max(4, int(n * args.keep_frac)), replace=False)).astype(np.uint32)
+    elif args.keep_stride:
+        kept = np.arange(0, n, args.keep_stride, dtype=np.uint32)
     elif args.keep_modulus:
         from pgen_rs_amd.synth import keep_indices
         kept = keep_indices(n, modulus=args.keep_modulus)
@@ -60,11 +67,19 @@ def main():
     if args.lines:
         rng = np.random.default_rng(2)
         plen = rng.integers(max(2, args.lines - 8), args.lines + 9, size=v).astype(np.int64)
+        if args.fold_rows or args.align_lines:
+            plen[:] = args.lines
         poff = np.concatenate([[0], np.cumsum(plen)]).astype(np.int64)
         loff = np.concatenate([[0], np.cumsum(plen + e0.gt_row_bytes)]).astype(np.int64)
+        if args.align_lines:
+            pitch = -(-(args.lines + e0.gt_row_bytes) // args.align_lines) * args.align_lines
+            loff = np.arange(v + 1, dtype=np.int64) * pitch
+        if args.fold_rows:
+            loff = loff[np.arange(v + 1) % args.fold_rows].copy()
+            loff[v] = loff.max() + args.lines + e0.gt_row_bytes
         blob = torch.full((int(poff[-1]) + 1,), 65, dtype=torch.uint8, device="cuda:0")
         lines = (blob, torch.from_numpy(poff).to("cuda:0"), torch.from_numpy(loff).to("cuda:0"), int(plen.max()))
-        out = torch.empty(int(loff[-1]), dtype=torch.uint8, device="cuda:0")
+        out = torch.empty(int(loff.max()) + 64, dtype=torch.uint8, device="cuda:0")
         alg = v * e0.record_size + 2 * int(poff[-1]) + v * e0.gt_row_bytes
     else:
         out = torch.empty(v * e0.gt_row_bytes, dtype=torch.uint8, device="cuda:0")
@@ -88,7 +103,7 @@ def main():
         torch.cuda.synchronize()
         digest = int(out[: out.numel() // 8 * 8].view(torch.int64).sum().item()) if out.numel() >= 8 else 0
         ref = digest if ref is None else ref
-        if digest != ref:
+        if digest != ref and not args.fold_rows:
             print(f"!! {spec}: output differs from the first arm")
     for _ in range(args.rounds):
         for spec, kern, eng in arms:
