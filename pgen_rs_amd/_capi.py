@@ -58,7 +58,7 @@ KNOB_ROWPICK_BLOCKS_PER_CU = 11
 KNOB_SCAN_ROWPICK = 12
 KNOB_PICK_LINE_SEAMS = 13
 KNOB_FLUSH_UNROLL = 14
-KNOB_SCAN_TEXT_MODE = 15
+KNOB_SCAN_FOUR_PICKS = 15
 
 
 

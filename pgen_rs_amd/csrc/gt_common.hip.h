@@ -153,8 +153,7 @@ __device__ __forceinline__ uint8_t *row_text(const EmitArgs &a, uint64_t j)
 // U chunks per lane and loop step: their 5 U table reads, then their 5 U staged-byte reads leave together, so a step costs two LDS
 // round trips whatever U is (the compiler does not unroll this loop by itself; with the segment kernel's two waves per SIMD the
 // round trips of U = 1 are exposed).
-// TEXT: `code_of` already yields the genotype's text dword (a kernel with a byte -> text table in LDS) instead of its 2-bit code.
-template <uint32_t U = 1, bool TEXT = false, typename CodeFn>
+template <uint32_t U = 1, typename CodeFn>
 __device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
                                             uint32_t seg_k0, uint32_t K, uint32_t lane)
 {
@@ -185,8 +184,7 @@ __device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8
         }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
-            const uint32_t t0 = TEXT ? c[u][0] : gt_text(c[u][0]), t1 = TEXT ? c[u][1] : gt_text(c[u][1]), t2 = TEXT ? c[u][2] : gt_text(c[u][2]),
-                           t3 = TEXT ? c[u][3] : gt_text(c[u][3]), t4 = TEXT ? c[u][4] : gt_text(c[u][4]);
+            const uint32_t t0 = gt_text(c[u][0]), t1 = gt_text(c[u][1]), t2 = gt_text(c[u][2]), t3 = gt_text(c[u][3]), t4 = gt_text(c[u][4]);
             const uint32_t sh = shv[u];
             gt_v4u v = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
             // the row's '\n' can only be a whole chunk's last byte (hi_emit <= 4K + 1)
@@ -199,7 +197,7 @@ __device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8
     if (on) {
         const uint32_t x = em + off;
         const uint32_t code = code_of(e4 + (x >> 2));
-        out0[off] = (uint8_t)(off == nl ? 0x0Au : TEXT ? (code >> (8u * (x & 3u))) & 0xFFu : gt_text_byte(code, x & 3u));
+        out0[off] = (uint8_t)(off == nl ? 0x0Au : gt_text_byte(code, x & 3u));
     }
 }
 

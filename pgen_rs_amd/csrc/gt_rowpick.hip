@@ -47,7 +47,7 @@ __host__ __device__ inline uint32_t codes_bytes(uint32_t K) { return ((K + 3u) /
 // COMPACT instantiation: instead of text the wave writes the row's compact record itself — ceil(K / 4) bytes at a.out + row *
 // a.out_stride, whole 16-byte chunks — the first pass of the two-pass path (capi.hip): an almost pure record reader, the text is
 // then written by the all-samples kernels from those records in a second, write-only pass.
-template <bool HAS_VIDX, bool COMPACT, uint32_t U>
+template <bool HAS_VIDX, bool COMPACT, uint32_t U, bool FOUR>
 __global__ __launch_bounds__(kThreads) void gt_rowpick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
@@ -191,7 +191,22 @@ __global__ __launch_bounds__(kThreads) void gt_rowpick_kernel(EmitArgs a, ScanAr
             row_out = a.out + row * a.out_stride;
         }
         const uint8_t *cd = codes;
-        flush_codes<U>([cd](uint32_t r) { return ((uint32_t)cd[r >> 2] >> ((r & 3u) * 2u)) & 3u; }, 0u, row_out, 0ull, 4ull * K + 1ull, 0u, K, lane);
+        if (FOUR) {
+            // four picks per chunk from ONE or two compact bytes, the fifth text from the next lane (flush_text4, gt_common.hip.h)
+            flush_text4<U>(
+                [cd](auto c0, uint32_t g, uint32_t &t0, uint32_t &t1, uint32_t &t2, uint32_t &t3) {
+                    constexpr uint32_t C0 = decltype(c0)::value;
+                    const uint32_t win = C0 == 0u ? (uint32_t)cd[g] : (uint32_t)cd[g] | ((uint32_t)cd[g + 1u] << 8);   // (the byte behind the record is slack)
+                    t0 = gt_text(__builtin_amdgcn_ubfe(win, 2u * C0, 2u));
+                    t1 = gt_text(__builtin_amdgcn_ubfe(win, 2u * C0 + 2u, 2u));
+                    t2 = gt_text(__builtin_amdgcn_ubfe(win, 2u * C0 + 4u, 2u));
+                    t3 = gt_text(__builtin_amdgcn_ubfe(win, 2u * C0 + 6u, 2u));
+                },
+                [cd](uint32_t r) -> uint32_t { return gt_text(((uint32_t)cd[r >> 2] >> ((r & 3u) * 2u)) & 3u); },
+                0u, row_out, 0ull, 4ull * K + 1ull, 0u, K, lane);
+        } else {
+            flush_codes<U>([cd](uint32_t r) { return ((uint32_t)cd[r >> 2] >> ((r & 3u) * 2u)) & 3u; }, 0u, row_out, 0ull, 4ull * K + 1ull, 0u, K, lane);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
@@ -271,10 +286,14 @@ bool plan(const EmitArgs &a, const Tuning &t, int num_cus, bool compact, RowPick
     L.n_seg = (a.sample_count + kSegSamples - 1u) / kSegSamples;
     if (L.n_seg < 1u || L.n_seg > 4096u || a.record_size < 16u) return false;
     L.lds = table_bytes(a.kept_count) + rank_bytes(L.n_seg) + (uint32_t)kWaves * (kStageBytes + codes_bytes(a.kept_count));
-    if (compact) L.kern = gathered(a) ? gt_rowpick_kernel<true, true, 1> : gt_rowpick_kernel<false, true, 1>;
-    else if (t.flush_unroll == 4) L.kern = gathered(a) ? gt_rowpick_kernel<true, false, 4> : gt_rowpick_kernel<false, false, 4>;
-    else if (t.flush_unroll == 2) L.kern = gathered(a) ? gt_rowpick_kernel<true, false, 2> : gt_rowpick_kernel<false, false, 2>;
-    else L.kern = gathered(a) ? gt_rowpick_kernel<true, false, 1> : gt_rowpick_kernel<false, false, 1>;
+    const bool g = gathered(a);
+    if (compact) L.kern = g ? gt_rowpick_kernel<true, true, 1, false> : gt_rowpick_kernel<false, true, 1, false>;
+    else if (t.scan_four_picks != 0)
+        L.kern = t.flush_unroll == 1 ? (g ? gt_rowpick_kernel<true, false, 1, true> : gt_rowpick_kernel<false, false, 1, true>)
+                                     : (g ? gt_rowpick_kernel<true, false, 2, true> : gt_rowpick_kernel<false, false, 2, true>);
+    else
+        L.kern = t.flush_unroll == 1 ? (g ? gt_rowpick_kernel<true, false, 1, false> : gt_rowpick_kernel<false, false, 1, false>)
+                                     : (g ? gt_rowpick_kernel<true, false, 2, false> : gt_rowpick_kernel<false, false, 2, false>);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L.kern, kThreads, L.lds) != hipSuccess || per_cu < 1) per_cu = 1;
     // two blocks per CU measure best on long records (the loads of 8 waves per CU already saturate the read path: tools/readbench.hip; 3:

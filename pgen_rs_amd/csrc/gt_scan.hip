@@ -66,24 +66,20 @@ constexpr uint32_t kStageBytes = kSegSamples / 4u;                   // one row'
 // SLOWER at 0.33-5 % kept: this kernel wants few, fat waves; profiles/r02_kernel_sweeps.md.)
 constexpr uint32_t kPickMaxSegCodes = kSegSamples;             // up to a fully kept segment: 32 KiB of LDS for the table
 
-// MODE: how a genotype's text comes out of the table entry and the staged record byte.
-//   0: entry = sample offset s; code = (stage[s >> 2] >> 2 (s & 3)) & 3, text by gt_text: 9 VALU + 2 LDS reads per genotype
-//   1: entry = byte offset << 4 | position << 2; text = s_lut[byte, position] (a 4-KiB byte -> text table): 3 VALU + 3 LDS reads
-//   2: entry = 2 x position << 12 | byte offset; code by v_bfe_u32, text by gt_text: 7 VALU + 2 LDS reads
-//   3: mode 2's entries fetched four at a time (one 16-byte LDS read per chunk) and FOUR picks per chunk, the fifth text from the
-//      next lane (flush_text4, gt_common.hip.h)
-template <bool HAS_VIDX, uint32_t U, int MODE>
+// FOUR (default): a table entry is 2 x position << 12 | byte offset (code by one v_bfe_u32); a chunk's four entries come with ONE
+// LDS read, it makes FOUR picks and takes its fifth text from the next lane (flush_text4, gt_common.hip.h): 45 VALU + 6 LDS
+// instructions per chunk where round 2's form (FOUR = false, kept for the A/B: entry = sample offset, five picks by shifts) has 64 +
+// 10.  Also tried (profiles/r03_kernel_sweeps.md §8): a 4-KiB byte -> text table in LDS (36 VALU + 15 LDS reads, LDS-bound),
+// bit-field extract alone (59 + 10), and a block-cooperative form with a loader wave (level).
+template <bool HAS_VIDX, uint32_t U, bool FOUR>
 __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups, uint32_t xcd_groups, uint32_t bands)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_idx[kPickMaxSegCodes + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][kStageBytes];
-    __shared__ uint32_t s_lut[MODE == 1 ? 1024 : 1];   // text of the genotype at position p of record byte b at [4 b + p]
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (MODE == 1)
-        for (uint32_t e = tid; e < 1024u; e += (uint32_t)kThreads) s_lut[e] = gt_text(((e >> 2) >> ((e & 3u) * 2u)) & 3u);   // src/pfile.rs:171-190
     // XCD-aware block -> (segment, row group) map: the pieces of ONE row are written by the blocks of one row group, and neighbouring
     // pieces share a 128-B line at every seam.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one), so with the
     // plain map b = row_group * n_seg + seg the two halves of a seam line come from two different L2s and reach memory as two partial
@@ -121,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
     }
     for (uint32_t r = tid; r < seg_cnt + 16u; r += (uint32_t)kThreads) {
         const uint32_t s16 = r < seg_cnt ? a.kept_idx[seg_k0 + r] - seg * kSegSamples : 0u;  // 16 entries of slack for the flush's fifth code / second group
-        s_idx[r] = (uint16_t)(MODE == 1 ? ((s16 >> 2) << 4) | ((s16 & 3u) << 2) : MODE >= 2 ? ((s16 & 3u) << 13) | (s16 >> 2) : s16);
+        s_idx[r] = (uint16_t)(FOUR ? ((s16 & 3u) << 13) | (s16 >> 2) : s16);
     }
     __syncthreads();
     if (rows == 0ull) return;
@@ -167,8 +163,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
         const uint64_t lo_emit = 4ull * seg_k0;
         const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
         const uint16_t *idx = s_idx;
-        const uint8_t *lut = reinterpret_cast<const uint8_t *>(s_lut);
-        if (MODE == 3) {
+        if (FOUR) {
             auto text_of = [stage](uint32_t e, uint32_t byte_lo, uint32_t shift_lo) {   // entry in bits [byte_lo, byte_lo + 12) and [shift_lo, shift_lo + 3)
                 return gt_text(__builtin_amdgcn_ubfe((uint32_t)stage[__builtin_amdgcn_ubfe(e, byte_lo, 12u)], __builtin_amdgcn_ubfe(e, shift_lo, 3u), 2u));
             };
@@ -192,12 +187,10 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
                 [idx, text_of](uint32_t r) -> uint32_t { return text_of(idx[r], 0u, 12u); },
                 0u, row_out, lo_emit, hi_emit, seg_k0, K, lane);
         } else {
-            flush_codes<U, MODE == 1>(
-                [stage, idx, lut](uint32_t r) -> uint32_t {
-                    const uint32_t e = idx[r];  // r <= seg_cnt + 4: inside the slack
-                    if (MODE == 1) return *reinterpret_cast<const uint32_t *>(lut + (((uint32_t)stage[e >> 4] << 4) | (e & 12u)));
-                    if (MODE == 2) return __builtin_amdgcn_ubfe((uint32_t)stage[e & 0xFFFu], e >> 12, 2u);
-                    return ((uint32_t)stage[e >> 2] >> ((e & 3u) * 2u)) & 3u;  // src/pfile.rs:171-175
+            flush_codes<U>(
+                [stage, idx](uint32_t r) -> uint32_t {
+                    const uint32_t s16 = idx[r];  // r <= seg_cnt + 4: inside the slack
+                    return ((uint32_t)stage[s16 >> 2] >> ((s16 & 3u) * 2u)) & 3u;  // src/pfile.rs:171-175
                 },
                 0u, row_out, lo_emit, hi_emit, seg_k0, K, lane);
         }
@@ -223,112 +216,6 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
         load_row(n + 1ull, b0, t0);
         emit_row(n, b1, t1);
         if (++n == rows) break;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// gt_scan_coop_kernel — the same pick, with the FOUR waves of a block working on ONE row piece at a time.
-// The per-wave kernel above keeps 4 x (resident blocks) rows in flight, each written 1 KiB at a time by one wave over ~30 steps:
-// the memory side sees ~2 000 thin write streams spread over 60 MB and takes them at ~4 TB/s, while the kernel itself could issue
-// half as much again (measured with the launch's lines folded onto one small window: profiles/r03_kernel_sweeps.md §8).  Here a
-// block stages a row's 4 KiB of segment bytes once (each wave loads one 1-KiB tile; two stages, so one barrier per row) and its
-// waves flush interleaved ranges of the piece: a quarter of the rows in flight, each piece written 4 U KiB at a time.
-template <bool HAS_VIDX, uint32_t U>
-__global__ __launch_bounds__(kThreads) void gt_scan_coop_kernel(EmitArgs a, ScanArgs sc, uint32_t n_seg, uint32_t row_groups, uint32_t xcd_groups, uint32_t bands)
-{
-    __shared__ __attribute__((aligned(16))) uint16_t s_idx[kPickMaxSegCodes + 16];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[2][kStageBytes];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool xcd_map = blockIdx.x < xcd_groups * n_seg;               // (block -> (segment, row group) as in gt_scan_pick_kernel)
-    const uint32_t b_plain = blockIdx.x - xcd_groups * n_seg;
-    const uint32_t seg = xcd_map ? (blockIdx.x >> 3) % n_seg : b_plain % n_seg;
-    const uint32_t row_group = xcd_map ? ((blockIdx.x >> 3) / n_seg) * 8u + (blockIdx.x & 7u) : xcd_groups + b_plain / n_seg;
-    const uint32_t K = a.kept_count;
-    const uint32_t seg_k0 = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg]);
-    const uint32_t seg_cnt = __builtin_amdgcn_readfirstlane(sc.seg_rank[seg + 1u]) - seg_k0;
-    const bool last_seg = seg + 1u == n_seg;
-    const uint32_t R = a.record_size;
-    const uint32_t band = row_group % bands, group_in_band = row_group / bands;
-    const uint64_t band_rows = ((uint64_t)a.n_variants + bands - 1u) / bands;
-    const uint64_t band_lo = (uint64_t)band * band_rows, band_hi = min((uint64_t)a.n_variants, band_lo + band_rows);
-    const uint64_t row_step = (uint64_t)(row_groups / bands);           // one row per block and step
-    const uint64_t j0 = band_lo + (uint64_t)group_in_band;
-    const uint64_t rows = j0 < band_hi ? (band_hi - j0 + row_step - 1ull) / row_step : 0ull;
-
-    if (a.line_off != nullptr) {
-        const uint32_t pfx_shift = prefix_copy_shift(a);
-        if (pfx_shift != 0u) copy_prefix_rows(a, pfx_shift, (uint64_t)blockIdx.x * kWaves + wave, (uint64_t)gridDim.x * kWaves, lane);
-    }
-    if (seg_cnt == 0u) {
-        if (last_seg)
-            for (uint64_t n = tid; n < rows; n += (uint64_t)kThreads) row_text(a, j0 + n * row_step)[4ull * K] = (uint8_t)'\n';
-        return;
-    }
-    for (uint32_t r = tid; r < seg_cnt + 16u; r += (uint32_t)kThreads) {
-        const uint32_t s16 = r < seg_cnt ? a.kept_idx[seg_k0 + r] - seg * kSegSamples : 0u;
-        s_idx[r] = (uint16_t)(((s16 & 3u) << 13) | (s16 >> 2));        // 2 x position << 12 | byte offset
-    }
-    if (rows == 0ull) return;                                            // (block-uniform)
-
-    // this wave's tile of the segment: tile `wave`, or the record's pulled-back tail window
-    const uint32_t tile = seg * kTilesPerSeg + wave;
-    const uint32_t tail_t = (R - 1u) >> 10;
-    const uint32_t tail_b = tail_t * 1024u + lane * 16u;
-    const uint32_t tail_off = min(tail_b, R - 16u);
-    const uint32_t tail_shift = tail_b + 16u <= R ? 0u : min(tail_b - (R - 16u), 16u);
-    const bool lines = a.line_off != nullptr;
-    auto load_row = [&](uint64_t n, v4u &dst, uint64_t &toff) {
-        const uint64_t row = j0 + min(n, rows - 1ull) * row_step;
-        if (lines) toff = a.line_off[row] + (a.prefix_off[row + 1ull] - a.prefix_off[row]);
-        const uint8_t *__restrict__ rec = HAS_VIDX ? gathered_record(a, row) : a.records + row * a.record_stride;
-        const uint8_t *src16 = tile < tail_t ? rec + (uint64_t)tile * 1024u + lane * 16u : rec + tail_off;
-        __builtin_memcpy(&dst, src16, 16);
-    };
-    const uint16_t *idx = s_idx;
-    v4u w;
-    uint64_t toff = 0ull;
-    load_row(0ull, w, toff);
-    for (uint64_t n = 0; n < rows; n++) {
-        uint8_t *const stage = s_stage[n & 1ull];
-        v4u x = w;
-        const uint64_t toff_n = toff;
-        if (tile == tail_t) {
-            uint64_t lo, hi;
-            window_halves(x, tail_shift, lo, hi);
-            x = v4u{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-        }
-        if (tile <= tail_t) *reinterpret_cast<v4u *>(stage + wave * 1024u + lane * 16u) = x;
-        load_row(n + 1ull, w, toff);                                     // the next row's tile is in flight while this row's text goes out
-        __syncthreads();                                                  // (also orders the table fill in front of the first flush)
-        uint8_t *const row_out = lines ? a.out + toff_n : a.out + (j0 + n * row_step) * a.out_stride;
-        const uint64_t lo_emit = 4ull * seg_k0;
-        const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
-        auto text_of = [stage](uint32_t e, uint32_t byte_lo, uint32_t shift_lo) {   // src/pfile.rs:171-190
-            return gt_text(__builtin_amdgcn_ubfe((uint32_t)stage[__builtin_amdgcn_ubfe(e, byte_lo, 12u)], __builtin_amdgcn_ubfe(e, shift_lo, 3u), 2u));
-        };
-        flush_text4<U>(
-            [idx, text_of](auto c0, uint32_t g, uint32_t &t0, uint32_t &t1, uint32_t &t2, uint32_t &t3) {
-                constexpr uint32_t C0 = decltype(c0)::value;
-                const uint32_t *grp = reinterpret_cast<const uint32_t *>(idx) + 2u * g;
-                uint32_t p01, p23;
-                if (C0 == 0u) { p01 = grp[0]; p23 = grp[1]; }
-                else if (C0 == 2u) { p01 = grp[1]; p23 = grp[2]; }
-                else {
-                    const uint32_t w0 = grp[C0 == 1u ? 0 : 1], w1 = grp[C0 == 1u ? 1 : 2], w2 = grp[C0 == 1u ? 2 : 3];
-                    p01 = __builtin_amdgcn_alignbyte(w1, w0, 2u);
-                    p23 = __builtin_amdgcn_alignbyte(w2, w1, 2u);
-                }
-                t0 = text_of(p01, 0u, 12u);
-                t1 = text_of(p01, 16u, 28u);
-                t2 = text_of(p23, 0u, 12u);
-                t3 = text_of(p23, 16u, 28u);
-            },
-            [idx, text_of](uint32_t r) -> uint32_t { return text_of(idx[r], 0u, 12u); },
-            0u, row_out, lo_emit, hi_emit, seg_k0, K, lane, wave, (uint32_t)kWaves);
-        // (stage n & 1 is rewritten two rows on, behind the next row's barrier: every wave has left this flush by then)
     }
 }
 
@@ -508,27 +395,10 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
     const bool g = gathered(a);
     auto by_mode = [&](auto u) -> Kern {
         constexpr uint32_t U = decltype(u)::value;
-        if (t.scan_text_mode == 1) return g ? gt_scan_pick_kernel<true, U, 1> : gt_scan_pick_kernel<false, U, 1>;
-        if (t.scan_text_mode == 2) return g ? gt_scan_pick_kernel<true, U, 2> : gt_scan_pick_kernel<false, U, 2>;
-        if (t.scan_text_mode == 3) return g ? gt_scan_pick_kernel<true, U, 3> : gt_scan_pick_kernel<false, U, 3>;
-        return g ? gt_scan_pick_kernel<true, U, 0> : gt_scan_pick_kernel<false, U, 0>;
+        if (t.scan_four_picks != 0) return g ? gt_scan_pick_kernel<true, U, true> : gt_scan_pick_kernel<false, U, true>;
+        return g ? gt_scan_pick_kernel<true, U, false> : gt_scan_pick_kernel<false, U, false>;
     };
-    const bool coop = t.scan_text_mode == 4;
-    if (coop) {
-        Kern ck = t.flush_unroll == 4 ? (g ? gt_scan_coop_kernel<true, 4> : gt_scan_coop_kernel<false, 4>)
-                  : t.flush_unroll == 2 ? (g ? gt_scan_coop_kernel<true, 2> : gt_scan_coop_kernel<false, 2>)
-                                        : (g ? gt_scan_coop_kernel<true, 1> : gt_scan_coop_kernel<false, 1>);
-        const uint64_t needed = (uint64_t)a.n_variants;                   // one row per block and step
-        const int pref = (uint64_t)a.kept_count * 170ull >= (uint64_t)a.sample_count ? 2 : 0;
-        uint64_t grp = (uint64_t)resident_blocks(ck, kThreads, num_cus, t, pref) / n_seg_eff;
-        if (grp < 1ull) grp = 1ull;
-        if (grp > needed) grp = needed;
-        const uint32_t xg = t.scan_xcd_map != 0 ? (uint32_t)(grp & ~7ull) : 0u;
-        const bool bnd = (uint64_t)a.kept_count * 10ull >= (uint64_t)a.sample_count && grp % 8ull == 0ull && needed >= 64ull * grp;
-        hipLaunchKernelGGL(ck, dim3((uint32_t)(grp * n_seg_eff)), dim3(kThreads), 0, stream, a, sc, n_seg_eff, (uint32_t)grp, xg, bnd ? 8u : 1u);
-        return hipGetLastError();
-    }
-    Kern kern = t.flush_unroll == 4 ? by_mode(std::integral_constant<uint32_t, 4>{}) : t.flush_unroll == 2 ? by_mode(std::integral_constant<uint32_t, 2>{}) : by_mode(std::integral_constant<uint32_t, 1>{});
+    Kern kern = t.flush_unroll == 1 ? by_mode(std::integral_constant<uint32_t, 1>{}) : by_mode(std::integral_constant<uint32_t, 2>{});
     const int preferred = (uint64_t)a.kept_count * 170ull >= (uint64_t)a.sample_count ? 2 : 0;
     uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus, t, preferred) / n_seg_eff;  // floor: never a partial second round
     if (groups < 1ull) groups = 1ull;  // more segments than resident blocks (N > ~16 M samples): rounds are unavoidable

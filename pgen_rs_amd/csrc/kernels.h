@@ -47,8 +47,8 @@ struct Tuning {
     int rowpick_blocks_per_cu = 0; // row-owner kernel: cap on resident blocks per CU (0 = what the occupancy API says)
     int scan_rowpick = 1;          // (1: row-owner compact pass + all-samples pass; 2: row-owner single pass; 0: segment compact pass)
          // sparse keeps on long records, many rows: one wave per row, one pass (0 = the segment kernels / two passes)
-    int flush_unroll = 2;          // segment / row-owner kernels: 16-byte chunks per lane and step of the text flush (1, 2, 4)
-    int scan_text_mode = 3;        // segment kernel: 3 four picks per chunk + the fifth text from the next lane (default); 0 / 1 / 2: five picks per chunk with shifts / a byte -> text table in LDS / bit-field extract; 4: the block-cooperative kernel
+    int flush_unroll = 2;          // segment / row-owner kernels: 16-byte chunks per lane and step of the text flush (1 or 2)
+    int scan_four_picks = 1;       // segment / row-owner kernels' text flush: four picks per chunk + the fifth text from the next lane (0 = round 2's five picks)
     int runs_rows = 0;             // RUNS mode of the stream kernel: rows per work item (0 = as many as one wide load / one span holds)
 };
 

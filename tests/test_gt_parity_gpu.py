@@ -1229,29 +1229,49 @@ def test_gt_segments_past_4_gib(n, v, keep_frac, pad):
         del out, rows2d
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("unroll", [1, 2, 4])
-def test_segment_kernel_text_modes_and_flush_unrolls(mode, unroll):
-    """The segment kernel's ways of turning (table entry, staged record byte) into text — shifts + arithmetic, the byte -> text
-    table in LDS, bit-field extract — with 1 / 2 / 4 chunks per lane and flush step: same bytes as the oracle for ragged record
-    tails, segments with 0 / 1 / all samples kept, every row alignment (odd K), with and without a gathered variant list."""
-    rng = np.random.default_rng(1000 + 10 * mode + unroll)
-    for n, dens, v in ((16385, 0.5, 37), (40_001, 0.93, 23), (70_003, 0.07, 29), (33_000, 1.0, 11)):
+@pytest.mark.parametrize("four", [1, -1])
+@pytest.mark.parametrize("unroll", [1, 2])
+@pytest.mark.parametrize("kernel", ["segment", "row_owner"])
+def test_text_flush_four_picks_and_unrolls(kernel, four, unroll):
+    """The subset kernels' text flush — four picks per 16-byte chunk with the fifth text from the next lane (wave_shl DPP, lane 63 from the
+    next group / the chunk behind the step), store instructions aligned to 128-byte lines; round 2's five picks — with 1 / 2 chunks per lane
+    and step: same bytes as the oracle for ragged record tails, segments with 0 / 1 / all samples kept, every row alignment and phase
+    (odd K: rows start at every byte offset mod 16), with and without a gathered variant list, GT segments and full lines."""
+    rng = np.random.default_rng(1000 + 10 * (four + 1) + unroll)
+    kern = _capi.KERNEL_SCAN if kernel == "segment" else _capi.KERNEL_ROWPICK
+    shapes = ((16385, 0.5, 37), (40_001, 0.93, 23), (70_003, 0.07, 29), (33_000, 1.0, 11)) if kernel == "segment" else ((16385, 0.5, 37), (70_003, 0.07, 29), (200_001, 0.08, 9))
+    for n, dens, v in shapes:
         r = oracle.variant_record_size(n)
         keep = rng.random(n) < dens
         keep[16384:16384 + 900] = False          # a stretch without kept samples across a segment boundary
         if n > 33_000:
-            keep[32768:32768 + 16384] = n % 2 == 0    # a segment that is empty (or wholly kept)
+            keep[32768:32768 + 16384] = n % 2 == 0 and kernel == "segment"    # a segment that is empty (or wholly kept)
         kept = np.flatnonzero(keep).astype(np.uint32)
         if kept.size == n:
             kept = kept[:-1]
         recs = rng.integers(0, 256, size=2 * v * r, dtype=np.uint8)
         vidx = rng.permutation(2 * v)[:v]
-        tune = {_capi.KNOB_SCAN_TEXT_MODE: mode, _capi.KNOB_FLUSH_UNROLL: unroll, _capi.KNOB_SCAN_BLOCKS_PER_CU: 1}
-        got, k = run_engine(recs, v, n, kept=kept, kernel=_capi.KERNEL_SCAN, tune=tune)
+        tune = {_capi.KNOB_SCAN_FOUR_PICKS: four, _capi.KNOB_FLUSH_UNROLL: unroll, _capi.KNOB_SCAN_BLOCKS_PER_CU: 1, _capi.KNOB_ROWPICK_BLOCKS_PER_CU: 1}
+        got, k = run_engine(recs, v, n, kept=kept, kernel=kern, tune=tune)
         want = oracle.decode_emit(recs[: v * r], v, n, kept_idx=kept)
         assert bytes(got[: want.size]) == want.tobytes(), (n, dens)
         assert (got[want.size :] == SENTINEL).all()
-        got, k = run_engine(recs, v, n, kept=kept, kernel=_capi.KERNEL_SCAN, tune=tune, variant_idx=vidx)
+        got, k = run_engine(recs, v, n, kept=kept, kernel=kern, tune=tune, variant_idx=vidx)
         want = oracle.decode_emit(recs.reshape(2 * v, r)[vidx].reshape(-1), v, n, kept_idx=kept)
         assert bytes(got[: want.size]) == want.tobytes(), (n, dens, "gathered")
+        # full lines with prefixes of every length mod 16 (every phase of the GT text against the 16-byte chunks and the 128-byte lines)
+        plen = ((np.arange(v) * 7 + 3) % 41 + 2).astype(np.int64)
+        poff = np.concatenate([[0], np.cumsum(plen)]).astype(np.int64)
+        loff = np.concatenate([[0], np.cumsum(plen + 4 * k + 1)]).astype(np.int64)
+        blob_np = rng.integers(65, 91, size=int(poff[-1]), dtype=np.uint8)
+        want_lines = oracle.emit_lines(recs[: v * r], v, n, blob_np, poff.astype(np.uint64), loff.astype(np.uint64), kept_idx=kept).tobytes()
+        with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+            for knob, value in tune.items():
+                eng.tune(knob, value)
+            out = torch.full((int(loff[-1]) + 64,), SENTINEL, dtype=torch.uint8, device=DEV)
+            eng.emit_lines(torch.from_numpy(recs[: v * r].copy()).to(DEV), v, torch.from_numpy(blob_np.copy()).to(DEV), torch.from_numpy(poff).to(DEV),
+                           torch.from_numpy(loff).to(DEV), int(plen.max()), out, kernel=kern)
+            eng.wait()
+            got_l = out.cpu().numpy()
+        assert bytes(got_l[: int(loff[-1])]) == want_lines, (n, dens, "lines")
+        assert (got_l[int(loff[-1]) :] == SENTINEL).all()
