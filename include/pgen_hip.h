@@ -223,6 +223,7 @@ typedef enum pgenhip_knob {
     PGENHIP_KNOB_PICK_LINE_SEAMS = 13,   /* short dense records, full lines: 1 (default) rows' interiors + batched seams (every byte written once in a whole chunk), -1 round 2's row-by-row flush */
     PGENHIP_KNOB_FLUSH_UNROLL = 14,      /* segment / row-owner kernels: 16-byte chunks per lane and step of the text flush (1 or 2; default 2) */
     PGENHIP_KNOB_SCAN_FOUR_PICKS = 15,   /* segment / row-owner kernels' text flush: 1 (default) four picks per 16-byte chunk, the fifth text from the next lane, table entries fetched four at a time; -1 round 2's five picks per chunk */
+    PGENHIP_KNOB_ALIGN_STORES = 16,      /* subset kernels (segment, row-owner, pick): 1 (default) lanes <-> chunks shifted so that every store instruction covers whole 128-byte lines, -1 from the run's first whole chunk */
     PGENHIP_KNOB_RUNS_ROWS = 7           /* RUNS kernel: rows per work item (default: as many as one wide load / one span holds) */
 } pgenhip_knob;
 int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value);

@@ -59,6 +59,7 @@ KNOB_SCAN_ROWPICK = 12
 KNOB_PICK_LINE_SEAMS = 13
 KNOB_FLUSH_UNROLL = 14
 KNOB_SCAN_FOUR_PICKS = 15
+KNOB_ALIGN_STORES = 16
 
 
 

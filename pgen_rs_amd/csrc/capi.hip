@@ -420,7 +420,7 @@ static int decode_emit_core(pgenhip_ctx *ctx, const void *d_records, uint64_t re
     rc = claim_counters(ctx, a);
     if (rc) return rc;
     const Tuning &t = ctx->tune;
-    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count};
+    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count, (uint32_t)ctx->tune.align_stores};
 
     switch (flags & PGENHIP_KERNEL_MASK) {
         case PGENHIP_KERNEL_AUTO:
@@ -509,7 +509,7 @@ int pgenhip_emit_lines(pgenhip_ctx *ctx, const void *d_records, uint64_t record_
     rc = claim_counters(ctx, a);
     if (rc) return rc;
     const Tuning &t = ctx->tune;
-    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count};
+    const ScanArgs sc{ctx->d_seg_rank, ctx->max_seg_count, (uint32_t)ctx->tune.align_stores};
     switch (flags) {
         case PGENHIP_KERNEL_AUTO:
             if (ctx->identity) a.kept_idx = nullptr;
@@ -586,6 +586,7 @@ int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value)
         case PGENHIP_KNOB_PICK_LINE_SEAMS: t.pick_line_seams = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_FLUSH_UNROLL: t.flush_unroll = value == 1 || value == 2 ? value : d.flush_unroll; break;
         case PGENHIP_KNOB_SCAN_FOUR_PICKS: t.scan_four_picks = value < 0 ? 0 : 1; break;
+        case PGENHIP_KNOB_ALIGN_STORES: t.align_stores = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_RUNS_ROWS: t.runs_rows = value > 0 ? value : d.runs_rows; break;
         default: return fail(PGENHIP_ERR_BAD_ARG, "unknown knob");
     }

@@ -213,9 +213,9 @@ __device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8
 // part, part + n_parts, ...: together they write 64 U n_parts chunks of contiguous text per round.
 template <uint32_t U, uint32_t C0, typename Text4Fn, typename Text1Fn>
 __device__ __forceinline__ void flush_text4_loop(Text4Fn texts4, Text1Fn text1, uint8_t *out0, uint32_t head, uint32_t n_chunks, uint32_t rel0,
-                                                 uint32_t sh, uint32_t rmax, uint32_t nl, uint32_t lane, uint32_t part, uint32_t n_parts)
+                                                 uint32_t sh, uint32_t rmax, uint32_t nl, uint32_t lane, uint32_t part, uint32_t n_parts, bool align)
 {
-    const uint32_t lead = __builtin_amdgcn_readfirstlane(((uint32_t)(uintptr_t)(out0 + head) >> 4) & 7u);
+    const uint32_t lead = align ? __builtin_amdgcn_readfirstlane(((uint32_t)(uintptr_t)(out0 + head) >> 4) & 7u) : 0u;
     const uint32_t t_last = text1(rmax);                                // the rank behind the last whole chunk
     for (uint32_t i0 = part * 64u * U; i0 < n_chunks + lead; i0 += n_parts * 64u * U) {
         uint32_t t[U][5], offv[U];
@@ -244,7 +244,7 @@ __device__ __forceinline__ void flush_text4_loop(Text4Fn texts4, Text1Fn text1, 
 
 template <uint32_t U, typename Text4Fn, typename Text1Fn>
 __device__ __forceinline__ void flush_text4(Text4Fn texts4, Text1Fn text1, uint32_t base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
-                                            uint32_t seg_k0, uint32_t K, uint32_t lane, uint32_t part = 0u, uint32_t n_parts = 1u)
+                                            uint32_t seg_k0, uint32_t K, uint32_t lane, bool align = true, uint32_t part = 0u, uint32_t n_parts = 1u)
 {
     uint8_t *const out0 = row_out + emitted;
     const uint32_t len = (uint32_t)(hi_emit - emitted);
@@ -263,10 +263,10 @@ __device__ __forceinline__ void flush_text4(Text4Fn texts4, Text1Fn text1, uint3
         const uint32_t sh = __builtin_amdgcn_readfirstlane(x0 & 3u);
         const uint32_t rmax = __builtin_amdgcn_readfirstlane(e4 + ((em + tail_off) >> 2));
         switch (rel0 & 3u) {
-            case 0u: flush_text4_loop<U, 0>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts); break;
-            case 1u: flush_text4_loop<U, 1>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts); break;
-            case 2u: flush_text4_loop<U, 2>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts); break;
-            default: flush_text4_loop<U, 3>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts); break;
+            case 0u: flush_text4_loop<U, 0>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
+            case 1u: flush_text4_loop<U, 1>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
+            case 2u: flush_text4_loop<U, 2>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
+            default: flush_text4_loop<U, 3>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
         }
     }
     if (part != 0u) return;                                             // the edges: the first of the cooperating waves

@@ -47,6 +47,7 @@ struct PickParams {
     uint32_t magic;       // floor(2^32 / S) + 1: o / S = umulhi(o, magic) for o < 2^20 (checked on the host), fixed up by one compare
     uint32_t n_batches;
     uint32_t pfx_shift;   // full lines: lanes per line (log2) of the in-kernel prefix copy, 0 = none
+    uint32_t align_stores; // Tuning::align_stores
     uint32_t packed;      // 1: dense records, no gather — a batch's B records are ONE contiguous run of B*R bytes, fetched KiB by KiB and
                           // parked as they lie (pitch = R): short records no longer cost a load instruction and a register quad per
                           // ROW, and a batch is up to 64 rows instead of 12 (N = 300 with 30 samples kept: 7.7 KB of text per batch, not 1.4)
@@ -281,7 +282,11 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
                 *reinterpret_cast<v4u *>(run + o) = t4;
             }
         } else
-        for (uint32_t c = lane; c < n_chunks; c += 64u) {
+        // (lanes <-> chunks shifted by `lead` so that every store instruction covers eight WHOLE 128-byte lines: one that starts
+        // mid-line touches nine, two of them partially — 5 % on write-dominated launches, profiles/r03_kernel_sweeps.md §8)
+        for (uint32_t c0 = 0, lead = p.align_stores ? ((uint32_t)(uintptr_t)(run + head) >> 4) & 7u : 0u; c0 < n_chunks + lead; c0 += 64u) {
+            const uint32_t c = c0 + lane - lead;                // (wraps for the lanes in front of chunk 0)
+            if (c >= n_chunks) continue;
             const uint32_t o = head + (c << 4);
             uint32_t i, pos;
             split_offset(o, p, i, pos);
@@ -565,6 +570,7 @@ hipError_t launch_gt_pick(const EmitArgs &a, const Tuning &t, int num_cus, hipSt
     p.pitch = p.pieces * 16u;
     p.row_bytes = 4u * a.kept_count + 1u;
     p.pfx_shift = prefix_copy_shift(a);
+    p.align_stores = t.align_stores != 0 ? 1u : 0u;
     // rows per batch: ~32 KiB of text per batch (8 / 16 / 32 / 64 KiB at 50 % kept on the chr22 shape: 1.44 / 1.41 / 1.37 / 1.36 ms),
     // what the stage holds, what the register buffer holds
     const uint32_t batch_bytes = t.pick_batch_bytes > 0 ? (uint32_t)t.pick_batch_bytes : 32768u;

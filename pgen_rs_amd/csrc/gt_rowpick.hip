@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void gt_rowpick_kernel(EmitArgs a, ScanAr
                     t3 = gt_text(__builtin_amdgcn_ubfe(win, 2u * C0 + 6u, 2u));
                 },
                 [cd](uint32_t r) -> uint32_t { return gt_text(((uint32_t)cd[r >> 2] >> ((r & 3u) * 2u)) & 3u); },
-                0u, row_out, 0ull, 4ull * K + 1ull, 0u, K, lane);
+                0u, row_out, 0ull, 4ull * K + 1ull, 0u, K, lane, sc.align_stores != 0u);
         } else {
             flush_codes<U>([cd](uint32_t r) { return ((uint32_t)cd[r >> 2] >> ((r & 3u) * 2u)) & 3u; }, 0u, row_out, 0ull, 4ull * K + 1ull, 0u, K, lane);
         }

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
                     t3 = text_of(p23, 16u, 28u);
                 },
                 [idx, text_of](uint32_t r) -> uint32_t { return text_of(idx[r], 0u, 12u); },
-                0u, row_out, lo_emit, hi_emit, seg_k0, K, lane);
+                0u, row_out, lo_emit, hi_emit, seg_k0, K, lane, sc.align_stores != 0u);
         } else {
             flush_codes<U>(
                 [stage, idx](uint32_t r) -> uint32_t {

@@ -49,6 +49,7 @@ struct Tuning {
          // sparse keeps on long records, many rows: one wave per row, one pass (0 = the segment kernels / two passes)
     int flush_unroll = 2;          // segment / row-owner kernels: 16-byte chunks per lane and step of the text flush (1 or 2)
     int scan_four_picks = 1;       // segment / row-owner kernels' text flush: four picks per chunk + the fifth text from the next lane (0 = round 2's five picks)
+    int align_stores = 1;          // subset kernels: lanes <-> chunks shifted so that every store instruction covers whole 128-byte lines (0 = from the first whole chunk)
     int runs_rows = 0;             // RUNS mode of the stream kernel: rows per work item (0 = as many as one wide load / one span holds)
 };
 
@@ -84,6 +85,7 @@ constexpr uint32_t kScanSegmentSamples = 16384u;
 struct ScanArgs {
     const uint32_t *seg_rank;    // device; n_segments + 1 entries
     uint32_t max_seg_count;      // most kept samples in any one segment
+    uint32_t align_stores;       // Tuning::align_stores
 };
 // The compact pass takes segments with at most this many kept samples (a quarter of a segment; the two-pass band is <= 4.5 %
 // kept overall, so only a very clustered list has more in one segment: capi.hip then stays with the single-pass kernel)
