@@ -171,6 +171,25 @@ def test_basic2_launches_of_several_blocks(basic2, tmp_path, block_mib, launch_m
     assert len(got) == len(want) and hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
 
 
+@pytest.mark.parametrize("extra", [[], ["--launch-mib", "4"], ["--bgzf", "--bgzf-level", "1"], ["--shards", "2"]])
+def test_write_error_in_the_middle_of_the_body_ends_the_run(basic2, tmp_path, extra):
+    """The consumer thread's write fails once the output passes 16 MiB (RLIMIT_FSIZE with SIGXFSZ ignored: EFBIG) while the producer is
+    staging / launching / queueing copies ahead of it: the run must end with the reference's panic status and the errno text — not hang
+    in one of the pipeline's waits, not exit 0 with a short file."""
+    import resource
+    import signal
+
+    def limit():
+        signal.signal(signal.SIGXFSZ, signal.SIG_IGN)
+        resource.setrlimit(resource.RLIMIT_FSIZE, (16 << 20, 16 << 20))
+
+    out = tmp_path / ("e.vcf.gz" if "--bgzf" in extra else "e.vcf")
+    # (BGZF at level 1 turns the 245 MB of text into ~41 MB: past the limit too)
+    p = subprocess.run([str(CLI), "filter", str(basic2), "-o", str(out), "--block-mib", "4", *extra], capture_output=True, timeout=300, preexec_fn=limit)
+    assert p.returncode == 101, (p.returncode, p.stderr[-500:])
+    assert b"File too large" in p.stderr or b"EFBIG" in p.stderr, p.stderr[-500:]
+
+
 # ---- a variable-width (mode 0x10) file through the CLI (SURVEY.md §8f N4) ---------------------------------------------
 @pytest.fixture(scope="module")
 def vw_pfile(tmp_path_factory):
