@@ -135,6 +135,10 @@ __device__ __forceinline__ void lds_flag_write(uint32_t off, uint32_t value)
 // ---- shared by the subset kernels (gt_scan.hip, gt_pick.hip) -------------------------------------
 typedef uint32_t gt_v4u __attribute__((ext_vector_type(4)));
 
+// The subset kernels' chunk stores: non-temporal like the stream kernel's (the text is not read again on the device; two libraries
+// alternated on one box, profiles/r03_logs/subset_nt_stores_ab.log: level to +3 %)
+__device__ __forceinline__ void subset_store16(uint8_t *dst, gt_v4u v) { __builtin_nontemporal_store(v, reinterpret_cast<gt_v4u *>(dst)); }
+
 // Byte 0 of row j's GT segment: out + j * out_stride, or — full-line mode (src/pfile.rs:156-192), any kept
 // subset — behind the line's prefix at out + line_off[j] + prefix length (the prefixes are copied by
 // copy_prefix_rows below, run by the GT kernels' own waves).  j is wave-uniform or per-lane.
@@ -189,7 +193,7 @@ __device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8
             gt_v4u v = {funnel_bytes(t0, t1, sh), funnel_bytes(t1, t2, sh), funnel_bytes(t2, t3, sh), funnel_bytes(t3, t4, sh)};
             // the row's '\n' can only be a whole chunk's last byte (hi_emit <= 4K + 1)
             if (offv[u] + 15u == nl) v.w = (v.w & 0x00FFFFFFu) | 0x0A000000u;
-            if (ok[u]) *reinterpret_cast<gt_v4u *>(out0 + offv[u]) = v;
+            if (ok[u]) subset_store16(out0 + offv[u], v);
         }
     }
     const uint32_t off = lane < 16u ? lane : tail_off + (lane - 16u);
@@ -237,7 +241,7 @@ __device__ __forceinline__ void flush_text4_loop(Text4Fn texts4, Text1Fn text1, 
             t[u][4] = last[u] ? t_last : lane == 63u ? from_next_group : from_next_lane;
             gt_v4u v = {funnel_bytes(t[u][0], t[u][1], sh), funnel_bytes(t[u][1], t[u][2], sh), funnel_bytes(t[u][2], t[u][3], sh), funnel_bytes(t[u][3], t[u][4], sh)};
             if (offv[u] + 15u == nl) v.w = (v.w & 0x00FFFFFFu) | 0x0A000000u;   // the row's '\n' can only be a whole chunk's last byte
-            if (ok[u]) *reinterpret_cast<gt_v4u *>(out0 + offv[u]) = v;
+            if (ok[u]) subset_store16(out0 + offv[u], v);
         }
     }
 }

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
                 v = u32x4{os[0], os[1], os[2], os[3]};
             }
             v4u t = {v.x, v.y, v.z, v.w};
-            *reinterpret_cast<v4u *>(run + o) = t;
+            subset_store16(run + o, gt_v4u{t.x, t.y, t.z, t.w});
         }
         {
             // edge bytes of the run: lanes 0-15 the head, lanes 16-31 the tail
