@@ -221,7 +221,7 @@ typedef enum pgenhip_knob {
     PGENHIP_KNOB_ROWPICK_BLOCKS_PER_CU = 11, /* row-owner kernel: cap on resident blocks per CU (default: occupancy API) */
     PGENHIP_KNOB_SCAN_ROWPICK = 12,      /* kept subsets on long records, launches of many rows: 1 (default) the row-owner kernel where it measures ahead (text in one pass for 2-20 % kept and for records of barely more than one segment; compact pass of the two passes below 2 %), 2 also in ONE pass across the two-pass band, -1 never (segment kernels) */
     PGENHIP_KNOB_PICK_LINE_SEAMS = 13,   /* short dense records, full lines: 1 (default) rows' interiors + batched seams (every byte written once in a whole chunk), -1 round 2's row-by-row flush */
-    PGENHIP_KNOB_FLUSH_UNROLL = 14,      /* segment / row-owner kernels: 16-byte chunks per lane and step of the text flush (1 or 2; default 2) */
+    PGENHIP_KNOB_FLUSH_UNROLL = 14,      /* segment / row-owner kernels: 16-byte chunks per lane and step of the text flush (1, 2 or 4 — 4 in the segment kernel only; default 2) */
     PGENHIP_KNOB_SCAN_FOUR_PICKS = 15,   /* segment / row-owner kernels' text flush: 1 (default) four picks per 16-byte chunk, the fifth text from the next lane, table entries fetched four at a time; -1 round 2's five picks per chunk */
     PGENHIP_KNOB_ALIGN_STORES = 16,      /* subset kernels (segment, row-owner, pick): 1 (default) lanes <-> chunks shifted so that every store instruction covers whole 128-byte lines, -1 from the run's first whole chunk */
     PGENHIP_KNOB_RUNS_ROWS = 7           /* RUNS kernel: rows per work item (default: as many as one wide load / one span holds) */

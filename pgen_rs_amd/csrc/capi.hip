@@ -584,7 +584,7 @@ int pgenhip_tune(pgenhip_ctx *ctx, uint32_t knob, int32_t value)
         case PGENHIP_KNOB_ROWPICK_BLOCKS_PER_CU: t.rowpick_blocks_per_cu = value > 0 ? value : d.rowpick_blocks_per_cu; break;
         case PGENHIP_KNOB_SCAN_ROWPICK: t.scan_rowpick = value < 0 ? 0 : (value == 2 ? 2 : 1); break;
         case PGENHIP_KNOB_PICK_LINE_SEAMS: t.pick_line_seams = value < 0 ? 0 : 1; break;
-        case PGENHIP_KNOB_FLUSH_UNROLL: t.flush_unroll = value == 1 || value == 2 ? value : d.flush_unroll; break;
+        case PGENHIP_KNOB_FLUSH_UNROLL: t.flush_unroll = value == 1 || value == 2 || value == 4 ? value : d.flush_unroll; break;
         case PGENHIP_KNOB_SCAN_FOUR_PICKS: t.scan_four_picks = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_ALIGN_STORES: t.align_stores = value < 0 ? 0 : 1; break;
         case PGENHIP_KNOB_RUNS_ROWS: t.runs_rows = value > 0 ? value : d.runs_rows; break;

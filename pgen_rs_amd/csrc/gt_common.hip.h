@@ -205,23 +205,68 @@ __device__ __forceinline__ void flush_codes(CodeFn code_of, uint32_t base, uint8
     }
 }
 
+// The four VARIABLE bytes of two genotypes' text — (allele 1, allele 2) of code ca, then of code cb — with three instructions
+// (v_lshl_or_b32, v_mad_u32_u24, v_perm_b32): selector byte 0 = ca (table A), byte 1 = 4 + ca (table B), bytes 2-3 the same for cb.
+__device__ __forceinline__ uint32_t gt_vars2(uint32_t ca, uint32_t cb)
+{
+    constexpr uint32_t kTabA = 0x2E313030u;  // '0','0','1','.'  (allele 1 char by code)
+    constexpr uint32_t kTabB = 0x2E313130u;  // '0','1','1','.'  (allele 2 char by code)
+    const uint32_t x = ca | (cb << 16);
+    uint32_t sel;   // (ca | cb << 16) * 0x0101 + 0x04000400; pinned: hipcc turns a plain multiply into the quarter-rate v_mul_lo_u32
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(sel) : "v"(x), "v"(0x0101u), "v"(0x04000400u));
+    return __builtin_amdgcn_perm(kTabB, kTabA, sel);
+}
+
 // The same flush for kernels whose picks come four at a time.  A 16-byte chunk holds the text of ranks rel .. rel+3 and, when the
 // flush's phase is not zero, leading bytes of rank rel+4 — which is the FIRST rank of the next chunk, i.e. of the next lane: it comes
 // over by a wavefront shift (v_mov_b32_dpp wave_shl:1) instead of a fifth pick, lane 63's from the next group of 64 chunks (one
 // extra single pick per step, for the chunk behind the step).  The four table entries of a chunk are consecutive:
-// `texts4(c0, g, t0..t3)` gets the flush-uniform C0 = rel & 3 as a std::integral_constant (four copies of the loop, chosen per flush by
-// a scalar branch) and the aligned group g = rel >> 2, and returns the texts of ranks 4g + C0 .. 4g + C0 + 3; `text1(rel)` returns one.
+// `codes4(c0, g, a, b, c, d)` gets the flush-uniform C0 = rel & 3 as a std::integral_constant (four copies of the loop, chosen per
+// flush by a scalar branch) and the aligned group g = rel >> 2, and returns the 2-bit codes of ranks 4g + C0 .. 4g + C0 + 3;
+// `code1(rel)` returns one.
 // Lane <-> chunk: lane l of group u of a step takes chunk i0 + 64 u + l - lead, where `lead` = the chunks between the 128-byte line
 // boundary at or below chunk 0 and chunk 0: every store instruction then covers eight WHOLE lines (a store that starts mid-line
-// touches nine, two of them partially: -5 % on write-dominated launches).  `part` of `n_parts` cooperating waves takes the steps
-// part, part + n_parts, ...: together they write 64 U n_parts chunks of contiguous text per round.
-template <uint32_t U, uint32_t C0, typename Text4Fn, typename Text1Fn>
-__device__ __forceinline__ void flush_text4_loop(Text4Fn texts4, Text1Fn text1, uint8_t *out0, uint32_t head, uint32_t n_chunks, uint32_t rel0,
+// touches nine, two of them partially).  `part` of `n_parts` cooperating waves takes the steps part, part + n_parts, ...
+// Steps whose every lane has a chunk and none the flush's last one — all but the first and the last — take the SHORT path: no
+// text dwords at all.  The chunk's variable bytes sit in three registers (gt_vars2: V0 = ranks 0-1, V1 = ranks 2-3, V2 = the next
+// lane's V0), and each of its four output dwords is ONE v_perm_b32 of a constant ('\t', '/') and V0 / V1 or their 2-byte
+// realignments, with a selector that depends only on the flush's phase: 13 instructions from codes to chunk where text dwords +
+// funnel shifts take 21, and no validity selects.
+template <uint32_t U, uint32_t C0, typename Codes4Fn, typename Code1Fn>
+__device__ __forceinline__ void flush_text4_loop(Codes4Fn codes4, Code1Fn code1, uint8_t *out0, uint32_t head, uint32_t n_chunks, uint32_t rel0,
                                                  uint32_t sh, uint32_t rmax, uint32_t nl, uint32_t lane, uint32_t part, uint32_t n_parts, bool align)
 {
     const uint32_t lead = align ? __builtin_amdgcn_readfirstlane(((uint32_t)(uintptr_t)(out0 + head) >> 4) & 7u) : 0u;
-    const uint32_t t_last = text1(rmax);                                // the rank behind the last whole chunk
+    const uint32_t t_last = gt_text(code1(rmax));                       // the rank behind the last whole chunk
+    // phase -> selectors of the even / odd output dwords (source bytes 0-3 = the variable-byte register, 4 = '\t', 5 = '/') and the
+    // realignment of the odd ones
+    const uint32_t sel_even = sh == 0u ? 0x01050004u : sh == 1u ? 0x04010500u : sh == 2u ? 0x02040105u : 0x05020401u;
+    const uint32_t sel_odd = sh == 0u ? 0x03050204u : sh == 1u ? 0x04030502u : sel_even;
+    const uint32_t realign = sh < 2u ? 0u : 2u;
+    constexpr uint32_t kConst = 0x00002F09u;                            // byte 0 = '\t', byte 1 = '/'
     for (uint32_t i0 = part * 64u * U; i0 < n_chunks + lead; i0 += n_parts * 64u * U) {
+        if ((i0 != 0u || lead == 0u) && i0 + 64u * U - lead < n_chunks) {
+            uint32_t V0[U], V1[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                uint32_t c0, c1, c2, c3;
+                codes4(std::integral_constant<uint32_t, C0>{}, (rel0 >> 2) + (i0 + u * 64u + lane - lead), c0, c1, c2, c3);
+                V0[u] = gt_vars2(c0, c1);
+                V1[u] = gt_vars2(c2, c3);
+            }
+            const uint32_t v_next = gt_vars2(code1(rel0 + 4u * (i0 + 64u * U - lead)), 0u);   // first rank of the chunk behind this step (wave-uniform)
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t from_next_lane = __builtin_amdgcn_update_dpp(0u, V0[u], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+                const uint32_t from_next_group = u + 1u < U ? (uint32_t)__builtin_amdgcn_readfirstlane(V0[u + 1u < U ? u + 1u : u]) : v_next;
+                const uint32_t V2 = lane == 63u ? from_next_group : from_next_lane;
+                const uint32_t X1 = __builtin_amdgcn_alignbyte(V1[u], V0[u], realign), X3 = __builtin_amdgcn_alignbyte(V2, V1[u], realign);
+                const gt_v4u v = {__builtin_amdgcn_perm(kConst, V0[u], sel_even), __builtin_amdgcn_perm(kConst, X1, sel_odd),
+                                  __builtin_amdgcn_perm(kConst, V1[u], sel_even), __builtin_amdgcn_perm(kConst, X3, sel_odd)};
+                subset_store16(out0 + head + ((i0 + u * 64u + lane - lead) << 4), v);
+            }
+            continue;
+        }
         uint32_t t[U][5], offv[U];
         bool ok[U], last[U];
 #pragma unroll
@@ -231,9 +276,14 @@ __device__ __forceinline__ void flush_text4_loop(Text4Fn texts4, Text1Fn text1, 
             last[u] = i + 1u == n_chunks;
             const uint32_t ii = ok[u] ? i : 0u;                         // (a lane without a chunk re-reads chunk 0's entries and stores nothing)
             offv[u] = head + (ii << 4);
-            texts4(std::integral_constant<uint32_t, C0>{}, (rel0 >> 2) + ii, t[u][0], t[u][1], t[u][2], t[u][3]);
+            uint32_t c0, c1, c2, c3;
+            codes4(std::integral_constant<uint32_t, C0>{}, (rel0 >> 2) + ii, c0, c1, c2, c3);
+            t[u][0] = gt_text(c0);
+            t[u][1] = gt_text(c1);
+            t[u][2] = gt_text(c2);
+            t[u][3] = gt_text(c3);
         }
-        const uint32_t t_next = text1(min(rel0 + 4u * (i0 + 64u * U - lead), rmax));   // first rank of the chunk behind this step (wave-uniform)
+        const uint32_t t_next = gt_text(code1(min(rel0 + 4u * (i0 + 64u * U - lead), rmax)));   // first rank of the chunk behind this step (wave-uniform)
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t from_next_lane = __builtin_amdgcn_update_dpp(0u, t[u][0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
@@ -246,8 +296,8 @@ __device__ __forceinline__ void flush_text4_loop(Text4Fn texts4, Text1Fn text1, 
     }
 }
 
-template <uint32_t U, typename Text4Fn, typename Text1Fn>
-__device__ __forceinline__ void flush_text4(Text4Fn texts4, Text1Fn text1, uint32_t base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
+template <uint32_t U, typename Codes4Fn, typename Code1Fn>
+__device__ __forceinline__ void flush_text4(Codes4Fn codes4, Code1Fn code1, uint32_t base, uint8_t *row_out, uint64_t emitted, uint64_t hi_emit,
                                             uint32_t seg_k0, uint32_t K, uint32_t lane, bool align = true, uint32_t part = 0u, uint32_t n_parts = 1u)
 {
     uint8_t *const out0 = row_out + emitted;
@@ -267,10 +317,10 @@ __device__ __forceinline__ void flush_text4(Text4Fn texts4, Text1Fn text1, uint3
         const uint32_t sh = __builtin_amdgcn_readfirstlane(x0 & 3u);
         const uint32_t rmax = __builtin_amdgcn_readfirstlane(e4 + ((em + tail_off) >> 2));
         switch (rel0 & 3u) {
-            case 0u: flush_text4_loop<U, 0>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
-            case 1u: flush_text4_loop<U, 1>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
-            case 2u: flush_text4_loop<U, 2>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
-            default: flush_text4_loop<U, 3>(texts4, text1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
+            case 0u: flush_text4_loop<U, 0>(codes4, code1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
+            case 1u: flush_text4_loop<U, 1>(codes4, code1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
+            case 2u: flush_text4_loop<U, 2>(codes4, code1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
+            default: flush_text4_loop<U, 3>(codes4, code1, out0, head, n_chunks, rel0, sh, rmax, nl, lane, part, n_parts, align); break;
         }
     }
     if (part != 0u) return;                                             // the edges: the first of the cooperating waves
@@ -278,7 +328,7 @@ __device__ __forceinline__ void flush_text4(Text4Fn texts4, Text1Fn text1, uint3
     const bool on = lane < 16u ? lane < head : (lane < 32u && lane - 16u < tail);
     if (on) {
         const uint32_t x = em + off;
-        out0[off] = (uint8_t)(off == nl ? 0x0Au : (text1(e4 + (x >> 2)) >> (8u * (x & 3u))) & 0xFFu);
+        out0[off] = (uint8_t)(off == nl ? 0x0Au : gt_text_byte(code1(e4 + (x >> 2)), x & 3u));
     }
 }
 

@@ -194,15 +194,15 @@ __global__ __launch_bounds__(kThreads) void gt_rowpick_kernel(EmitArgs a, ScanAr
         if (FOUR) {
             // four picks per chunk from ONE or two compact bytes, the fifth text from the next lane (flush_text4, gt_common.hip.h)
             flush_text4<U>(
-                [cd](auto c0, uint32_t g, uint32_t &t0, uint32_t &t1, uint32_t &t2, uint32_t &t3) {
+                [cd](auto c0, uint32_t g, uint32_t &k0, uint32_t &k1, uint32_t &k2, uint32_t &k3) {
                     constexpr uint32_t C0 = decltype(c0)::value;
                     const uint32_t win = C0 == 0u ? (uint32_t)cd[g] : (uint32_t)cd[g] | ((uint32_t)cd[g + 1u] << 8);   // (the byte behind the record is slack)
-                    t0 = gt_text(__builtin_amdgcn_ubfe(win, 2u * C0, 2u));
-                    t1 = gt_text(__builtin_amdgcn_ubfe(win, 2u * C0 + 2u, 2u));
-                    t2 = gt_text(__builtin_amdgcn_ubfe(win, 2u * C0 + 4u, 2u));
-                    t3 = gt_text(__builtin_amdgcn_ubfe(win, 2u * C0 + 6u, 2u));
+                    k0 = __builtin_amdgcn_ubfe(win, 2u * C0, 2u);
+                    k1 = __builtin_amdgcn_ubfe(win, 2u * C0 + 2u, 2u);
+                    k2 = __builtin_amdgcn_ubfe(win, 2u * C0 + 4u, 2u);
+                    k3 = __builtin_amdgcn_ubfe(win, 2u * C0 + 6u, 2u);
                 },
-                [cd](uint32_t r) -> uint32_t { return gt_text(((uint32_t)cd[r >> 2] >> ((r & 3u) * 2u)) & 3u); },
+                [cd](uint32_t r) -> uint32_t { return ((uint32_t)cd[r >> 2] >> ((r & 3u) * 2u)) & 3u; },
                 0u, row_out, 0ull, 4ull * K + 1ull, 0u, K, lane, sc.align_stores != 0u);
         } else {
             flush_codes<U>([cd](uint32_t r) { return ((uint32_t)cd[r >> 2] >> ((r & 3u) * 2u)) & 3u; }, 0u, row_out, 0ull, 4ull * K + 1ull, 0u, K, lane);

@@ -67,8 +67,8 @@ constexpr uint32_t kStageBytes = kSegSamples / 4u;                   // one row'
 constexpr uint32_t kPickMaxSegCodes = kSegSamples;             // up to a fully kept segment: 32 KiB of LDS for the table
 
 // FOUR (default): a table entry is 2 x position << 12 | byte offset (code by one v_bfe_u32); a chunk's four entries come with ONE
-// LDS read, it makes FOUR picks and takes its fifth text from the next lane (flush_text4, gt_common.hip.h): 45 VALU + 6 LDS
-// instructions per chunk where round 2's form (FOUR = false, kept for the A/B: entry = sample offset, five picks by shifts) has 64 +
+// LDS read, it makes FOUR picks and takes its fifth genotype from the next lane (flush_text4, gt_common.hip.h): 40 VALU + 6.5 LDS
+// instructions per chunk where round 2's form (FOUR = false, kept for the A/B: entry = sample offset, five picks by shifts) has 70 +
 // 10.  Also tried (profiles/r03_kernel_sweeps.md §8): a 4-KiB byte -> text table in LDS (36 VALU + 15 LDS reads, LDS-bound),
 // bit-field extract alone (59 + 10), and a block-cooperative form with a loader wave (level).
 template <bool HAS_VIDX, uint32_t U, bool FOUR>
@@ -164,11 +164,11 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
         const uint64_t hi_emit = 4ull * ((uint64_t)seg_k0 + seg_cnt) + (last_seg ? 1ull : 0ull);  // '\n' closes the row (:190)
         const uint16_t *idx = s_idx;
         if (FOUR) {
-            auto text_of = [stage](uint32_t e, uint32_t byte_lo, uint32_t shift_lo) {   // entry in bits [byte_lo, byte_lo + 12) and [shift_lo, shift_lo + 3)
-                return gt_text(__builtin_amdgcn_ubfe((uint32_t)stage[__builtin_amdgcn_ubfe(e, byte_lo, 12u)], __builtin_amdgcn_ubfe(e, shift_lo, 3u), 2u));
+            auto code_of = [stage](uint32_t e, uint32_t byte_lo, uint32_t shift_lo) {   // entry in bits [byte_lo, byte_lo + 12) and [shift_lo, shift_lo + 3)
+                return __builtin_amdgcn_ubfe((uint32_t)stage[__builtin_amdgcn_ubfe(e, byte_lo, 12u)], __builtin_amdgcn_ubfe(e, shift_lo, 3u), 2u);   // src/pfile.rs:171-175
             };
             flush_text4<U>(
-                [idx, text_of](auto c0, uint32_t g, uint32_t &t0, uint32_t &t1, uint32_t &t2, uint32_t &t3) {
+                [idx, code_of](auto c0, uint32_t g, uint32_t &k0, uint32_t &k1, uint32_t &k2, uint32_t &k3) {
                     constexpr uint32_t C0 = decltype(c0)::value;
                     const uint32_t *grp = reinterpret_cast<const uint32_t *>(idx) + 2u * g;     // 8-byte aligned; the second group may be slack
                     uint32_t p01, p23;                                                            // entries (r, r+1), (r+2, r+3)
@@ -179,12 +179,12 @@ __global__ __launch_bounds__(kThreads) void gt_scan_pick_kernel(EmitArgs a, Scan
                         p01 = __builtin_amdgcn_alignbyte(w1, w0, 2u);
                         p23 = __builtin_amdgcn_alignbyte(w2, w1, 2u);
                     }
-                    t0 = text_of(p01, 0u, 12u);
-                    t1 = text_of(p01, 16u, 28u);
-                    t2 = text_of(p23, 0u, 12u);
-                    t3 = text_of(p23, 16u, 28u);
+                    k0 = code_of(p01, 0u, 12u);
+                    k1 = code_of(p01, 16u, 28u);
+                    k2 = code_of(p23, 0u, 12u);
+                    k3 = code_of(p23, 16u, 28u);
                 },
-                [idx, text_of](uint32_t r) -> uint32_t { return text_of(idx[r], 0u, 12u); },
+                [idx, code_of](uint32_t r) -> uint32_t { return code_of(idx[r], 0u, 12u); },
                 0u, row_out, lo_emit, hi_emit, seg_k0, K, lane, sc.align_stores != 0u);
         } else {
             flush_codes<U>(
@@ -398,7 +398,7 @@ hipError_t launch_gt_scan(const EmitArgs &a, const ScanArgs &sc, const Tuning &t
         if (t.scan_four_picks != 0) return g ? gt_scan_pick_kernel<true, U, true> : gt_scan_pick_kernel<false, U, true>;
         return g ? gt_scan_pick_kernel<true, U, false> : gt_scan_pick_kernel<false, U, false>;
     };
-    Kern kern = t.flush_unroll == 1 ? by_mode(std::integral_constant<uint32_t, 1>{}) : by_mode(std::integral_constant<uint32_t, 2>{});
+    Kern kern = t.flush_unroll == 1 ? by_mode(std::integral_constant<uint32_t, 1>{}) : t.flush_unroll == 4 ? by_mode(std::integral_constant<uint32_t, 4>{}) : by_mode(std::integral_constant<uint32_t, 2>{});
     const int preferred = (uint64_t)a.kept_count * 170ull >= (uint64_t)a.sample_count ? 2 : 0;
     uint64_t groups = (uint64_t)resident_blocks(kern, kThreads, num_cus, t, preferred) / n_seg_eff;  // floor: never a partial second round
     if (groups < 1ull) groups = 1ull;  // more segments than resident blocks (N > ~16 M samples): rounds are unavoidable

@@ -25,7 +25,9 @@ __device__ __forceinline__ v4u make_text(uint32_t seed, uint32_t work)
 
 // SEGMENT-kernel pattern: rows of `row_bytes`, cut into `pieces` pieces; block = 4 waves, owns piece p of the rows of its row group;
 // wave w of row group g writes piece p of rows 4 g + w, 4 g + w + 4 G, ...: U KiB per step, the piece front to back.
-template <int U, bool NT>
+// DRAIN: the wave waits for all its stores at the end of every piece (what a load behind the stores costs the segment kernel:
+// gfx9 has one counter for loads and stores, and the compiler waits vmcnt(0) for a load that follows stores in a loop)
+template <int U, bool NT, bool DRAIN = false, bool JITTER = false>
 __global__ __launch_bounds__(256) void seg_pattern(uint8_t *out, uint64_t rows, uint32_t row_bytes, uint32_t pieces, uint32_t groups, uint32_t work)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -36,14 +38,18 @@ __global__ __launch_bounds__(256) void seg_pattern(uint8_t *out, uint64_t rows, 
         uint8_t *dst = out + row * row_bytes + (uint64_t)p * piece_bytes + lane * 16u;
         for (uint32_t s = 0; s < steps; s++) {
             v4u v[U];
+            // JITTER: the work per step varies by +-50 % from wave to wave and step to step (do waves that all take equally long per step
+            // fall into lock step and send their stores in bursts?)
+            const uint32_t w_s = JITTER ? work / 2u + (((uint32_t)row * 2654435761u + s * 40503u + blockIdx.x * 97u + wave * 31u) >> 7) % (work + 1u) : work;
 #pragma unroll
-            for (int u = 0; u < U; u++) v[u] = make_text((uint32_t)row + s * 64u + lane + u, work);
+            for (int u = 0; u < U; u++) v[u] = make_text((uint32_t)row + s * 64u + lane + u, w_s);
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 v4u *q = reinterpret_cast<v4u *>(dst + (s * U + u) * 1024u);
                 if (NT) __builtin_nontemporal_store(v[u], q); else *q = v[u];
             }
         }
+        if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
@@ -101,8 +107,8 @@ int main(int argc, char **argv)
     unsigned long long *heads; CK(hipMalloc(&heads, 8 * 16 * sizeof(unsigned long long)));
     printf("rows %llu x %u bytes = %.2f GB\n", (unsigned long long)rows, row_bytes, total / 1e9);
     const int cus = 256;
-    for (uint32_t work : {0u, 8u, 16u, 32u}) {
-        for (int per_cu : {1, 2, 3, 4, 8}) {
+    for (uint32_t work : {0u, 8u, 16u, 24u}) {
+        for (int per_cu : {2, 3, 4}) {
             for (uint32_t pieces : {7u, 28u}) {
                 const uint32_t groups = std::max(1u, (uint32_t)(per_cu * cus) / pieces);
                 auto run = [&](auto kern, const char *name) {
@@ -112,6 +118,8 @@ int main(int argc, char **argv)
                 run(seg_pattern<1, false>, "U1");
                 run(seg_pattern<2, true>, "U2 nt");
                 run(seg_pattern<4, true>, "U4 nt");
+                run(seg_pattern<2, true, true>, "U2 nt drain");
+                run(seg_pattern<2, true, false, true>, "U2 nt jitter");
             }
             for (uint32_t item_kib : {16u, 4u}) {
                 const uint64_t n_items = total / (item_kib * 1024ull);
