@@ -8,6 +8,7 @@
 // (filter: write the VCF header only and report the body geometry; needs no GPU); BGZF output (`-o x.vcf.gz` or --bgzf,
 // --bgzf-level <1-9>, --compress-threads <T>) and `pgen-hip bgzf <IN> <OUT>`, the same writer on a file.
 // Exit codes: 0 ok; 2 usage error (clap's code); 101 where the reference would panic.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -200,6 +201,7 @@ Args parse(int argc, char **argv, int first, const std::vector<std::pair<std::st
 
 int main(int argc, char **argv)
 {
+    const auto t_main = std::chrono::steady_clock::now();
     if (argc < 2) usage_error("a subcommand is required");
     const std::string cmd = argv[1];
     try {
@@ -271,9 +273,10 @@ int main(int argc, char **argv)
             if (a.has("stats")) {
                 std::fprintf(stderr,
                              "{\"variants_kept\": %llu, \"samples_kept\": %llu, \"header_bytes\": %llu, \"body_bytes\": %llu, "
-                             "\"file_bytes\": %llu, \"seconds_filter\": %.6f, \"seconds_body\": %.6f, \"seconds_kernel\": %.6f}\n",
+                             "\"file_bytes\": %llu, \"seconds_filter\": %.6f, \"seconds_body\": %.6f, \"seconds_setup\": %.6f, \"seconds_kernel\": %.6f, \"seconds_main\": %.6f}\n",
                              (unsigned long long)st.variants, (unsigned long long)st.samples_kept, (unsigned long long)st.header_bytes,
-                             (unsigned long long)st.body_bytes, (unsigned long long)st.file_bytes, st.seconds_filter, st.seconds_body, st.seconds_kernel);
+                             (unsigned long long)st.body_bytes, (unsigned long long)st.file_bytes, st.seconds_filter, st.seconds_body, st.seconds_setup, st.seconds_kernel,
+                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count());
             }
             return 0;
         }

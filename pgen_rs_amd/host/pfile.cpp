@@ -488,7 +488,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     const double t_body = now_s();
     std::mutex err_mu;
     std::string err;
-    std::vector<double> kernel_s((size_t)G, 0.0);
+    std::vector<double> kernel_s((size_t)G, 0.0), setup_s((size_t)G, 0.0);
     std::vector<uint64_t> shard_out((size_t)G, 0);   // BGZF: compressed bytes per shard
     const std::string pgen = pgen_path();
 
@@ -503,6 +503,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
 
     auto worker = [&](int g) {
         try {
+            const double t_worker = now_s();
             // contiguous range of the kept-variant list per device, sizes differ by <= 1: the one partitioner
             uint64_t begin64 = 0, end64 = 0;
             check(pgenhip_shard_range(V, (uint32_t)G, (uint32_t)g, &begin64, &end64), "pgenhip_shard_range");
@@ -763,6 +764,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
                 if (!consumer_err.empty()) throw PfileError(consumer_err);
             };
 
+            setup_s[(size_t)g] = now_s() - t_worker;
             for (size_t j = 0; j < plan[0].n_blocks; j++) stage_block(0, j);
             launch(0);
             for (size_t u = 0; u < plan.size(); u++) {
@@ -807,6 +809,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
     close_checked();
     st.seconds_body = now_s() - t_body;
     st.seconds_kernel = *std::max_element(kernel_s.begin(), kernel_s.end());
+    st.seconds_setup = *std::max_element(setup_s.begin(), setup_s.end());
     return st;
 }
 

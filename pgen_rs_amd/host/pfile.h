@@ -41,6 +41,7 @@ struct OutputStats {
     uint64_t variants = 0, samples_kept = 0, header_bytes = 0, body_bytes = 0;   // header / body: bytes of VCF text
     uint64_t file_bytes = 0;                                                     // what the output file holds (BGZF: compressed)
     double seconds_filter = 0, seconds_body = 0, seconds_kernel = 0;
+    double seconds_setup = 0;   // inside seconds_body: HIP runtime start, contexts, device and pinned allocations of the slowest shard, before its first block is staged
 };
 
 class Pfile {
