@@ -69,9 +69,15 @@ template <bool IDENT>
 __device__ __forceinline__ uint32_t pick_code(const uint8_t *row, const uint16_t *idx, int32_t rank, uint32_t K)
 {
     (void)K;
-    const uint32_t s = IDENT ? (uint32_t)max(rank, 0) : (uint32_t)idx[rank];
+    if (!IDENT) {
+        // table entry = 2 x (position in the byte) << 12 | byte offset in the record (pick_entry below): one v_bfe_u32 per code
+        const uint32_t e = idx[rank];
+        return __builtin_amdgcn_ubfe((uint32_t)row[e & 0xFFFu], e >> 12, 2u);   // src/pfile.rs:171-175
+    }
+    const uint32_t s = (uint32_t)max(rank, 0);
     return ((uint32_t)row[s >> 2] >> ((s & 3u) * 2u)) & 3u;
 }
+__device__ __forceinline__ uint16_t pick_entry(uint32_t sample) { return (uint16_t)(((sample & 3u) << 13) | (sample >> 2)); }
 
 // 16 text bytes of staged row `row` starting at row byte q (q may be negative: the bytes before the row are don't-care)
 template <bool IDENT>
@@ -89,18 +95,23 @@ __device__ __forceinline__ u32x4 pick_text16(const uint8_t *row, const uint16_t 
         }
         return gt_text16_from_window(window, (int64_t)q);
     }
+    // five picks, no text dwords: the variable bytes of genotypes (0, 1), (2, 3), (4) in three registers (gt_vars2), their 2-byte
+    // realignments for the odd dwords, and ONE selector for all four output dwords — bytes [sh, sh + 4) of the selector sequence
+    // '\t', a1, '/', a2, '\t', a1', '/', a2' of a genotype pair (4 = '\t', 5 = '/', 0-3 = the pair register's bytes): 36 VALU
+    // instructions per chunk where text dwords + funnel shifts + the old shift-and-mask picks took 56
     const int32_t g = q >> 2;  // floor
     const uint32_t sh = (uint32_t)q & 3u;
-    const uint32_t t0 = gt_text(pick_code<false>(row, idx, g, K));
-    const uint32_t t1 = gt_text(pick_code<false>(row, idx, g + 1, K));
-    const uint32_t t2 = gt_text(pick_code<false>(row, idx, g + 2, K));
-    const uint32_t t3 = gt_text(pick_code<false>(row, idx, g + 3, K));
-    const uint32_t t4 = gt_text(pick_code<false>(row, idx, g + 4, K));
+    const uint32_t V0 = gt_vars2(pick_code<false>(row, idx, g, K), pick_code<false>(row, idx, g + 1, K));
+    const uint32_t V1 = gt_vars2(pick_code<false>(row, idx, g + 2, K), pick_code<false>(row, idx, g + 3, K));
+    const uint32_t V2 = gt_vars2(pick_code<false>(row, idx, g + 4, K), 0u);
+    const uint32_t X1 = __builtin_amdgcn_alignbyte(V1, V0, 2u), X3 = __builtin_amdgcn_alignbyte(V2, V1, 2u);
+    const uint32_t sel = __builtin_amdgcn_alignbyte(0x03050204u, 0x01050004u, sh);
+    constexpr uint32_t kConst = 0x00002F09u;                            // byte 0 = '\t', byte 1 = '/'
     u32x4 v;
-    v.x = funnel_bytes(t0, t1, sh);
-    v.y = funnel_bytes(t1, t2, sh);
-    v.z = funnel_bytes(t2, t3, sh);
-    v.w = funnel_bytes(t3, t4, sh);
+    v.x = __builtin_amdgcn_perm(kConst, V0, sel);
+    v.y = __builtin_amdgcn_perm(kConst, X1, sel);
+    v.z = __builtin_amdgcn_perm(kConst, V1, sel);
+    v.w = __builtin_amdgcn_perm(kConst, X3, sel);
     return v;
 }
 
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_kernel(EmitArgs a, PickParam
     const uint32_t K = a.kept_count;
     if (!IDENT) {
         for (uint32_t r = tid; r < kPadBefore + K + kPadAfter; r += (uint32_t)kThreads)
-            s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? (uint16_t)a.kept_idx[r - kPadBefore] : (uint16_t)0;
+            s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? pick_entry(a.kept_idx[r - kPadBefore]) : (uint16_t)0;
     }
     for (uint32_t r = tid; r < (uint32_t)kWaves * (kMaxPackedRows + 1) * 8u; r += (uint32_t)kThreads) (&s_heads[0][0])[r] = 0u;
     __syncthreads();
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void gt_pick_lines_kernel(EmitArgs a, Pic
     const uint32_t K = a.kept_count;
     if (!IDENT) {
         for (uint32_t r = tid; r < kPadBefore + K + kPadAfter; r += (uint32_t)kThreads)
-            s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? (uint16_t)a.kept_idx[r - kPadBefore] : (uint16_t)0;
+            s_tab[r] = r >= kPadBefore && r < kPadBefore + K ? pick_entry(a.kept_idx[r - kPadBefore]) : (uint16_t)0;
     }
     __syncthreads();
     const uint16_t *const s_idx = s_tab + kPadBefore;
