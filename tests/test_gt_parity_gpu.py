@@ -1146,11 +1146,11 @@ def test_randomized_differential_auto_dispatch(seed):
             raise AssertionError(f"{tag}: {bad.size} bytes differ, first at {bad[:8]}")
 
 
-@pytest.mark.parametrize("n,v,keep_mod", [(300, 4_300_000, 0), (2504, 500_000, 0), (900, 1_350_000, 0), (40_000, 900_000, 29)])
+@pytest.mark.parametrize("n,v,keep_mod", [(300, 4_300_000, 0), (2504, 500_000, 0), (900, 1_350_000, 0), (40_000, 900_000, 29), (100_000, 26_000, 2), (60_000, 235_000, 12)])
 def test_emit_lines_past_4_gib(n, v, keep_mod):
     """Full lines whose offsets pass 2^32 in ONE call (5.3 GB of text at the reference's own 300-sample shape through the line-run
     kernel, 5.0 GB at N = 2 504 through the stream kernel, 4.9 GB at N = 900 through the pick kernel, 5 GB through the two-pass
-    path): every kernel carries run- / row-relative offsets in 32 bits and the place of the run in 64.  Checked against the oracle
+    path, 5.2 GB through the segment kernel's four-pick flush at half of 100 000 samples kept, 4.4 GB through the row-owner kernel at 8 % of 60 000): every kernel carries run- / row-relative offsets in 32 bits and the place of the run in 64.  Checked against the oracle
     on windows of lines at the start, around the 4-GiB mark, at the end and at random places; LF at the end of every line
     and sentinels behind the last one."""
     free, _ = torch.cuda.mem_get_info()
@@ -1275,3 +1275,32 @@ def test_text_flush_four_picks_and_unrolls(kernel, four, unroll):
             got_l = out.cpu().numpy()
         assert bytes(got_l[: int(loff[-1])]) == want_lines, (n, dens, "lines")
         assert (got_l[int(loff[-1]) :] == SENTINEL).all()
+
+
+@pytest.mark.parametrize("n,v,keep_mod", [(100_000, 26_000, 2), (60_000, 235_000, 12), (2504, 950_000, 2)])
+def test_gt_segments_of_kept_subsets_past_4_gib(n, v, keep_mod):
+    """GT segments of kept subsets whose output passes 2^32 bytes in one call: the segment kernel (half of 100 000 samples), the
+    row-owner kernel (8 % of 60 000) and the short-record pick kernel (half of 2 504) — row- / piece-relative offsets in 32 bits, the
+    row's place in 64.  LF at the end of every row over the whole buffer, sentinels behind it, byte equality with the oracle on rows
+    at the start, around the 4-GiB mark and at the end."""
+    kept = oracle.synth_keep(n, modulus=keep_mod)
+    k = int(kept.size)
+    row = 4 * k + 1
+    total = v * row
+    assert total > (1 << 32) + (1 << 27)
+    free, _ = torch.cuda.mem_get_info()
+    if free < total + v * oracle.variant_record_size(n) + (3 << 30):
+        pytest.skip("needs records and output resident")
+    with pgen_rs_amd.GtEngine(n, kept_idx=kept, device=0) as eng:
+        recs = eng.synth_records(v)
+        out = torch.full((total + 64,), SENTINEL, dtype=torch.uint8, device=DEV)
+        eng.decode_emit(recs, v, out=out)
+        eng.wait()
+        assert (out[total:] == SENTINEL).all().item()
+        assert (out[row - 1 : total : row] == 10).all().item()
+        assert (out[0:total:row] == 9).all().item()
+        j_4g = (1 << 32) // row
+        for j in (0, 1, j_4g - 1, j_4g, j_4g + 1, v // 2, v - 2, v - 1):
+            got = out[j * row : (j + 1) * row].cpu().numpy()
+            host = oracle.synth_records(n, 1, first_variant=j)
+            assert got.tobytes() == oracle.decode_emit(host, 1, n, kept_idx=kept).tobytes(), f"row {j}"
