@@ -375,6 +375,24 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
 {
     OutputStats st;
     const double t0 = now_s();
+    // The HIP runtime's first call (device discovery, loading the code object) costs 30-80 ms: let it run beside the metadata walk
+    // instead of in front of the first block.  A throw-away ctx on every device this run will use; errors are left to the real
+    // creates below, which report them.
+    std::thread hip_warm_up([n = std::max(1, opt.n_gpus)] {
+        int n_dev = 0;
+        if (pgenhip_device_count(&n_dev) != PGENHIP_OK) return;
+        for (int d = 0; d < std::min(n, n_dev); d++) {
+            pgenhip_ctx *c = nullptr;
+            if (pgenhip_create(&c, d, 4, nullptr, 0, 0) == PGENHIP_OK) pgenhip_destroy(c);
+        }
+    });
+    struct WarmUpJoin {
+        std::thread &t;
+        ~WarmUpJoin()
+        {
+            if (t.joinable()) t.join();
+        }
+    } warm_up_join{hip_warm_up};
     const std::string psam = read_file(psam_path());  // :111
     TsvReader psam_reader(psam, find_metadata_file_header_start(psam));
     const StringRecord sam_header = psam_reader.headers();  // :112
@@ -480,6 +498,7 @@ OutputStats Pfile::output_vcf(const std::optional<std::string> &sam_query, const
         return st;
     }
 
+    if (hip_warm_up.joinable()) hip_warm_up.join();
     int n_dev = 0;
     check(pgenhip_device_count(&n_dev), "pgenhip_device_count");
     if (n_dev <= 0) throw PfileError("no HIP device: the GT decode/emit path has no CPU fallback");
