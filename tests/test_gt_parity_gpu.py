@@ -1230,12 +1230,12 @@ def test_gt_segments_past_4_gib(n, v, keep_frac, pad):
 
 
 @pytest.mark.parametrize("four", [1, -1])
-@pytest.mark.parametrize("unroll", [1, 2])
+@pytest.mark.parametrize("unroll", [1, 2, 4])
 @pytest.mark.parametrize("kernel", ["segment", "row_owner"])
 def test_text_flush_four_picks_and_unrolls(kernel, four, unroll):
     """The subset kernels' text flush — four picks per 16-byte chunk with the fifth text from the next lane (wave_shl DPP, lane 63 from the
-    next group / the chunk behind the step), store instructions aligned to 128-byte lines; round 2's five picks — with 1 / 2 chunks per lane
-    and step: same bytes as the oracle for ragged record tails, segments with 0 / 1 / all samples kept, every row alignment and phase
+    next group / the chunk behind the step), store instructions aligned to 128-byte lines; round 2's five picks — with 1 / 2 / 4 chunks per lane
+    and step (4: the segment kernel only): same bytes as the oracle for ragged record tails, segments with 0 / 1 / all samples kept, every row alignment and phase
     (odd K: rows start at every byte offset mod 16), with and without a gathered variant list, GT segments and full lines."""
     rng = np.random.default_rng(1000 + 10 * (four + 1) + unroll)
     kern = _capi.KERNEL_SCAN if kernel == "segment" else _capi.KERNEL_ROWPICK
