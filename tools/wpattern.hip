@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void seg_pattern(uint8_t *out, uint64_t rows, 
 // The segment pattern with its reads gathered into BURSTS: the wave reads the 4-KiB record segments of RB of its rows at once
 // (RB x 4 loads of 16 B per lane), then writes those RB pieces without another read ("few, large read bursts disturb the HBM write
 // stream far less than many small ones", gt_wide.hip).
-template <int U, int RB>
+template <int U, int RB, bool NTLOAD = false>
 __global__ __launch_bounds__(256) void seg_pattern_burst(uint8_t *out, uint64_t rows, uint32_t row_bytes, uint32_t pieces, uint32_t groups, uint32_t work, const uint8_t *recs)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -79,8 +79,16 @@ __global__ __launch_bounds__(256) void seg_pattern_burst(uint8_t *out, uint64_t 
         for (int b = 0; b < RB; b++) {
             const uint64_t row = min(row0 + (uint64_t)b * row_step, rows - 1ull);
             const uint8_t *src = recs + (row * pieces + p) * 4096ull + lane * 16u;
-            v4u r0 = *reinterpret_cast<const v4u *>(src), r1 = *reinterpret_cast<const v4u *>(src + 1024), r2 = *reinterpret_cast<const v4u *>(src + 2048),
+            v4u r0, r1, r2, r3;
+            if (NTLOAD) {
+                r0 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src));
+                r1 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src + 1024));
+                r2 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src + 2048));
+                r3 = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src + 3072));
+            } else {
+                r0 = *reinterpret_cast<const v4u *>(src); r1 = *reinterpret_cast<const v4u *>(src + 1024); r2 = *reinterpret_cast<const v4u *>(src + 2048);
                 r3 = *reinterpret_cast<const v4u *>(src + 3072);
+            }
             mix[b] = (r0.x ^ r1.y ^ r2.z ^ r3.w) & 1u;
         }
 #pragma unroll
@@ -182,6 +190,7 @@ int main(int argc, char **argv)
                 run_burst(seg_pattern_burst<2, 4>, "read burst 4");
                 run_burst(seg_pattern_burst<2, 8>, "read burst 8");
                 run_burst(seg_pattern_burst<2, 16>, "read burst 16");
+                run_burst((seg_pattern_burst<2, 1, true>), "read nt-load");
                 {
                     double ms = time_ms([&] { hipLaunchKernelGGL((seg_pattern<2, true, false, false, true>), dim3(groups * pieces), dim3(256), 0, 0, out, rows, row_bytes, pieces, groups, work, recs); }, 5);
                     printf("seg   work %2u  blocks/CU %d  pieces %2u  %-8s %7.3f ms  %.2f TB/s (writes; + %.0f %% read)\n", work, per_cu, pieces, "U2 nt read", ms, total / ms / 1e9, 100.0 * 4096.0 * pieces / row_bytes);
